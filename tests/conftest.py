@@ -1,0 +1,64 @@
+"""pytest configuration: `gpu` marker + shared fixtures.
+
+`-m "not gpu"` runs on the GPU-less build container (oracle vs golden vectors, host logic, C-ABI
+symbol checks, gloo sharding); `-m gpu` are the parity tests proper and call the HIP kernels
+through the C-ABI on a real MI355X.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def all_golden_names():
+    return sorted(f[len("golden_"):-len(".npz")] for f in os.listdir(GOLDEN_DIR)
+                  if f.startswith("golden_") and f.endswith(".npz"))
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"golden_{name}.npz")))
+
+
+def make_robot(name):
+    """Rebuild the robot a golden fixture was generated with (see oracle/gen_golden.py)."""
+    from rbdreference_amd.robot import BUILTIN_ROBOTS, random_tree
+    if name in BUILTIN_ROBOTS:
+        return BUILTIN_ROBOTS[name]()
+    if name == "random_tree_n9":
+        return random_tree([-1, 0, 1, 1, 3, -1, 5, 5, 7], seed=7, name=name)
+    if name == "random_prismatic_n6":
+        return random_tree([-1, 0, 1, 2, 2, 4], seed=11, prismatic_every=3, name=name)
+    raise KeyError(name)
+
+
+def rel_err(x, ref):
+    """Per-tensor normwise relative error  max|x - ref| / max|ref|  (SURVEY.md §8d)."""
+    x = np.asarray(x, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    d = np.max(np.abs(x - ref)) if x.size else 0.0
+    s = np.max(np.abs(ref)) if ref.size else 0.0
+    return d / s if s > 0 else d
+
+
+def rel_err_rows(x, ref):
+    """Per-row (per-configuration) normwise relative error; returns the worst row."""
+    x = np.asarray(x, dtype=np.float64).reshape(x.shape[0], -1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(ref.shape[0], -1)
+    d = np.max(np.abs(x - ref), axis=1)
+    s = np.max(np.abs(ref), axis=1)
+    return float(np.max(d / np.where(s > 0, s, 1.0)))
+
+
+@pytest.fixture(params=all_golden_names())
+def golden_case(request):
+    name = request.param
+    return name, make_robot(name), load_golden(name)
