@@ -1,0 +1,20 @@
+"""rbdreference_amd -- MI355X-native batched rigid-body dynamics behind the RBDReference API.
+
+    from rbdreference_amd import RBDReference, iiwa_like
+    rbd = RBDReference(iiwa_like())
+    c, dc_du = rbd.rnea_grad(q, qd, qdd, return_c=True)      # q, qd, qdd: [B, 7] cuda tensors
+"""
+from .robot import (BUILTIN_ROBOTS, Link, Robot, atlas_like, builtin_robot, iiwa_like,
+                    quadruped_like, random_tree)
+from .packer import PackedModel, pack_robot
+
+__all__ = ["RBDReference", "Robot", "Link", "iiwa_like", "quadruped_like", "atlas_like",
+           "random_tree", "builtin_robot", "BUILTIN_ROBOTS", "pack_robot", "PackedModel"]
+
+
+def __getattr__(name):
+    # api.py imports torch; keep `import rbdreference_amd` light for the packer / build tools
+    if name == "RBDReference":
+        from .api import RBDReference
+        return RBDReference
+    raise AttributeError(name)

@@ -1,0 +1,87 @@
+"""ctypes binding of the per-robot C-ABI library (include/rbd_hip.h).
+
+There is NO fallback: if the library for a robot cannot be found or built, or exports the wrong
+model, this module raises.  The oracle under /oracle is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int, c_int32,
+                    c_int64, c_size_t, c_uint64, c_void_p)
+
+from .build import build_model, lib_path
+from .packer import ABI_VERSION, PackedModel
+
+RBD_MAX_BODIES = 64
+RBD_ERR_ARG, RBD_ERR_UNSUPPORTED, RBD_ERR_WORKSPACE = -1, -2, -3
+
+# every symbol include/rbd_hip.h declares (tests check the built library exports all of them)
+EXPORTED_SYMBOLS = [
+    "rbd_abi_version", "rbd_last_error", "rbd_model_info",
+    "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
+    "rbd_minv_workspace_bytes", "rbd_minv_f32", "rbd_minv_f64",
+]
+
+
+class RbdModelInfo(Structure):
+    _fields_ = [("abi_version", c_int32), ("n", c_int32), ("max_depth", c_int32),
+                ("hash", c_uint64), ("name", c_char * 64),
+                ("parent", c_int32 * RBD_MAX_BODIES), ("joint_type", c_int32 * RBD_MAX_BODIES),
+                ("joint_axis", c_int32 * RBD_MAX_BODIES)]
+
+
+class RbdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rbd C-ABI error {code}: {msg}")
+        self.code = code
+
+
+def _declare(lib):
+    lib.rbd_abi_version.restype = c_int
+    lib.rbd_abi_version.argtypes = []
+    lib.rbd_last_error.restype = c_char_p
+    lib.rbd_last_error.argtypes = []
+    lib.rbd_model_info.restype = c_int
+    lib.rbd_model_info.argtypes = [POINTER(RbdModelInfo)]
+    for sfx, ft in (("f32", c_float), ("f64", c_double)):
+        f = getattr(lib, f"rbd_rnea_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_void_p,
+                      c_void_p, c_void_p]
+        f = getattr(lib, f"rbd_rnea_grad_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int, c_int64, c_void_p, c_void_p, c_void_p]
+        f = getattr(lib, f"rbd_minv_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.rbd_minv_workspace_bytes.restype = c_size_t
+    lib.rbd_minv_workspace_bytes.argtypes = [c_int64, c_int]
+
+
+class RbdLibrary:
+    """A loaded per-robot library, checked against the packed model it is meant to serve."""
+
+    def __init__(self, model: PackedModel, build: bool = True):
+        path = lib_path(model)
+        if build:
+            path = build_model(model)            # no-op when up to date; raises if hipcc is missing
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"HIP library for robot {model.name!r} (hash {model.hash}) not found at {path}; "
+                "build it with rbdreference_amd.build.build_model() -- there is no CPU fallback")
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        _declare(self.lib)
+        if self.lib.rbd_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI {self.lib.rbd_abi_version()} != {ABI_VERSION}")
+        info = RbdModelInfo()
+        self.check(self.lib.rbd_model_info(ctypes.byref(info)))
+        if info.n != model.n or f"{info.hash:016x}" != model.hash or \
+                list(info.parent[:model.n]) != list(model.parent):
+            raise RuntimeError(f"{path}: compiled-in model does not match robot {model.name!r}")
+        self.info = info
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise RbdError(rc, (self.lib.rbd_last_error() or b"").decode())

@@ -1,0 +1,128 @@
+"""Per-robot build of the HIP library: packed model -> generated header -> hipcc (gfx950) -> .so.
+
+Libraries land IN-TREE under ``rbdreference_amd/_build/`` (git-ignored, but they travel with the
+gpurun snapshot), named ``librbd_<name>_<hash>.so``; the hash covers every model constant, so a
+stale library can never be picked up for a changed robot.  ``python -m rbdreference_amd.build``
+prebuilds the three built-in robots (what ``__graft_entry__.build()`` calls).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import threading
+from typing import Optional
+
+from .packer import PackedModel, emit_header, pack_robot
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD_DIR = os.path.join(HERE, "_build")
+ARCH = "gfx950"
+
+HIPCC_FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-fno-signed-zeros",          # lets structural zeros fold; the sign of a zero is never observable here
+    "-munsafe-fp-atomics",        # LDS float adds lower to ds_add_f32 / ds_add_f64, never CAS loops
+    "-Wno-unused-value",
+]
+
+
+def hipcc_path() -> str:
+    p = os.environ.get("RBD_HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found (set RBD_HIPCC); the per-robot HIP library cannot be built")
+    return p
+
+
+def lib_path(m: PackedModel) -> str:
+    safe = "".join(ch if ch.isalnum() or ch == "_" else "_" for ch in m.name)
+    return os.path.join(BUILD_DIR, f"librbd_{safe}_{m.hash}.so")
+
+
+def header_path(m: PackedModel) -> str:
+    return os.path.join(BUILD_DIR, f"model_{m.hash}.h")
+
+
+def _sources_mtime() -> float:
+    t = 0.0
+    for f in os.listdir(CSRC):
+        t = max(t, os.path.getmtime(os.path.join(CSRC, f)))
+    t = max(t, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "rbd_hip.h")))
+    return t
+
+
+TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64"]
+_HIPCC_SLOTS = threading.BoundedSemaphore(max(1, (os.cpu_count() or 2)))
+
+
+def _run(cmd, what):
+    with _HIPCC_SLOTS:
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=BUILD_DIR)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({what}):\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return r
+
+
+def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
+                extra_flags: Optional[list] = None) -> str:
+    """Compile the library for packed model `m` (no-op when an up-to-date one exists).  The single
+    source file is compiled as seven translation units in parallel (-DRBD_TU_*) and linked."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    out = lib_path(m)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= _sources_mtime():
+        return out
+    hdr = header_path(m)
+    with open(hdr, "w") as f:
+        f.write(emit_header(m))
+    src = os.path.join(CSRC, "rbd_kernels.hip")
+    flags = list(HIPCC_FLAGS) + list(extra_flags or [])
+
+    def compile_tu(tu):
+        obj = os.path.join(BUILD_DIR, f"obj_{m.hash}_{tu}.o")
+        cmd = [hipcc_path(), *[f for f in flags if f != "-shared"], f"-DRBD_TU_{tu}=1", "-include", hdr,
+               "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = _run(cmd, f"{m.name} {tu}")
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(TRANSLATION_UNITS)) as ex:
+        objs = list(ex.map(compile_tu, TRANSLATION_UNITS))
+    _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out + ".tmp"],
+         f"{m.name} link")
+    os.replace(out + ".tmp", out)
+    for o in objs:
+        os.remove(o)
+    return out
+
+
+def build_models_parallel(models, force: bool = False, jobs: Optional[int] = None) -> list:
+    """Build several per-robot libraries concurrently (one hipcc process each)."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = jobs or max(1, len(models))      # hipcc processes are throttled by _HIPCC_SLOTS
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        return list(ex.map(lambda m: build_model(m, force=force), models))
+
+
+def build_robot(robot, name: Optional[str] = None, **kw) -> str:
+    return build_model(pack_robot(robot, name), **kw)
+
+
+def build_builtins(force: bool = False, verbose: bool = False) -> list:
+    from .robot import BUILTIN_ROBOTS
+    return [build_robot(mk(), force=force, verbose=verbose) for mk in BUILTIN_ROBOTS.values()]
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-v", "--verbose", action="store_true")
+    a = ap.parse_args()
+    for p in build_builtins(a.force, a.verbose):
+        print(p)

@@ -1,0 +1,672 @@
+// rbd_kernels.hip -- per-robot HIP kernels (gfx950 / CDNA4) + the C-ABI of include/rbd_hip.h.
+//
+// Compiled once per robot:  hipcc --offload-arch=gfx950 -include <generated model header> ...
+// (rbdreference_amd/build.py).  The path restated here is RBDReference.rnea / rnea_grad / minv,
+// /root/reference/RBDReference.py:559-806, 1127-1368; line cites below are into that file.
+//
+// Work mapping:
+//   rnea        one configuration per lane; outputs transposed through LDS for coalesced stores.
+//   rnea_grad   TWO lanes per configuration: even lane = d/dq columns, odd lane = d/dqd columns.
+//               Both run the same instruction stream (the two recursions differ only in their seed
+//               terms, :1159/:1173 vs :1231/:1243).  The reference's backward passes (:1257-1343)
+//               are replaced by the equivalent forward identity
+//                   dc[i, c] = sum_{j in subtree(i) & subtree(c)} Phi[i, j]^T df[c, j],
+//                   Phi[i, j] = X_{j<-i} S_i = dv_dqd[:, i, j]
+//               so no (6, n, NB) df tensor is ever stored: each body contributes 6-term dot
+//               products that are accumulated straight into an LDS image of the output tile, which
+//               is then written to HBM with fully coalesced stores.
+#include "rbd_spatial.h"
+
+namespace rbdk {
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged coalesced store: each of the block's 64 lanes holds K values of its configuration
+// (global layout [cfg][K], row-major).  Lanes park them in LDS (row stride KP, odd => conflict
+// free), then the wave streams the tile out linearly, 64 consecutive elements per instruction.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+constexpr int odd_pad() { return (K % 2 == 0) ? K + 1 : K; }
+
+template <int K, class T>
+RBD_DEV void staged_store(T* lds, const T (&vals)[K], T* gdst, int lane, int nvalid) {
+  constexpr int KP = odd_pad<K>();
+  __syncthreads();  // previous users of `lds` are done
+  sfor<0, K>([&](auto I) { lds[lane * KP + decltype(I)::value] = vals[decltype(I)::value]; });
+  __syncthreads();
+  const int total = nvalid * K;
+#pragma unroll 4
+  for (int g = lane; g < total; g += 64) {
+    int cfg = g / K;
+    int r = g - cfg * K;
+    gdst[g] = lds[cfg * KP + r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rnea:  (q, qd, qdd) -> c [B,n], v, a, f [B,6,n]   (f = ACCUMULATED force, :619, :628)
+// ---------------------------------------------------------------------------------------------
+template <class T, bool HAS_QDD, bool WITH_VAF>
+__global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+                                                  const T* __restrict__ qdd, T grav, long long B,
+                                                  T* __restrict__ c_out, T* __restrict__ v_out,
+                                                  T* __restrict__ a_out, T* __restrict__ f_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const long long cfg0 = (long long)blockIdx.x * 64;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < 64 ? (int)rem : 64;
+  const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
+
+  JTrig<T> tr[N];
+  T qdv[N], qddv[N];
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    tr[j] = make_trig<j>(q[b * N + j]);
+    qdv[j] = qd[b * N + j];
+    if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
+  });
+
+  T v[N][6], a[N][6], f[N][6];
+  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    T xv[6], xa[6];
+    if constexpr (p < 0)
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
+    else
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
+  });
+  // backward pass (:607-619)
+  T c[N];
+  sfor_down<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    c[j] = S_dot<j>(f[j]);
+    if constexpr (p >= 0) {
+      T t[6];
+      xform_T<j>(tr[j], f[j], t);
+      sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+    }
+  });
+
+  staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
+  if constexpr (WITH_VAF) {
+    // reference layout (6, NB) per configuration: element [r][i]
+    T tmp[6 * N];
+    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = v[decltype(J)::value][decltype(R)::value]; }); });
+    staged_store<6 * N>(lds, tmp, v_out + cfg0 * 6 * N, lane, nvalid);
+    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = a[decltype(J)::value][decltype(R)::value]; }); });
+    staged_store<6 * N>(lds, tmp, a_out + cfg0 * 6 * N, lane, nvalid);
+    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
+    staged_store<6 * N>(lds, tmp, f_out + cfg0 * 6 * N, lane, nvalid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rnea_grad: (q, qd, qdd) -> c [B,n] (optional), dc_du = [dc_dq | dc_dqd]  [B, n, 2n]  (:1345-1368)
+// ---------------------------------------------------------------------------------------------
+constexpr int GRAD_ROW = 2 * N;               // one output row: [dc_dq[i,:] | dc_dqd[i,:]]
+constexpr int GRAD_TILE = 2 * N * N;          // floats per configuration
+// LDS stride between configurations: == 2 (mod 32) keeps the 16 configurations of a 32-lane
+// LDS group on distinct even banks; the odd lane's +N offset lands on the odd banks when N is odd.
+constexpr int grad_tile_stride() {
+  int s = GRAD_TILE;
+  while (s % 32 != 2) ++s;
+  return s;
+}
+constexpr int GRAD_TS = grad_tile_stride();
+// Configurations per block (two lanes each): 32 = one full wave when the LDS tiles fit, otherwise
+// the largest power of two whose tiles fit in 160 KiB (big robots: partially filled wave, slow but
+// correct -- DESIGN.md "next").
+template <class T>
+constexpr int grad_cfgs() {
+  int c = 32;
+  while (c > 1 && (long long)c * GRAD_TS * (long long)sizeof(T) > 160 * 1024) c /= 2;
+  return c;
+}
+
+template <class T>
+RBD_DEV T from_odd_lane(T x);
+template <>
+RBD_DEV float from_odd_lane<float>(float x) {
+  // DPP quad_perm [1,1,3,3]: every lane reads the odd lane of its pair
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xF5, 0xF, 0xF, true));
+}
+template <>
+RBD_DEV double from_odd_lane<double>(double x) {
+  unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int lo = __builtin_amdgcn_mov_dpp((int)(u & 0xffffffffu), 0xF5, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_mov_dpp((int)(u >> 32), 0xF5, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <class T>
+RBD_DEV void lds_add(T* p, T v) { atomicAdd(p, v); }
+
+template <class T, bool HAS_QDD>
+__global__ __launch_bounds__(2 * grad_cfgs<T>()) void rnea_grad_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+                                                       const T* __restrict__ qdd, T grav, int use_damping,
+                                                       long long B, T* __restrict__ c_out,
+                                                       T* __restrict__ dcdu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const int slot = lane >> 1;
+  const bool isqd = (lane & 1) != 0;
+  constexpr int CFGS = grad_cfgs<T>();
+  constexpr int NT = 2 * CFGS;
+  const long long cfg0 = (long long)blockIdx.x * CFGS;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < CFGS ? (int)rem : CFGS;
+  const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
+
+  JTrig<T> tr[N];
+  T qdv[N], qddv[N];
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    tr[j] = make_trig<j>(q[b * N + j]);
+    qdv[j] = qd[b * N + j];
+    if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
+  });
+
+  // ---- RNEA forward + backward: v, a, X v_p, X a_p per body and the ACCUMULATED forces -------
+  T v[N][6], a[N][6], xv[N][6], xa[N][6], f[N][6];
+  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    if constexpr (p < 0)
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv[j], xa[j], v[j], a[j], f[j]);
+    else
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv[j], xa[j], v[j], a[j], f[j]);
+  });
+  T c[N];
+  sfor_down<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    c[j] = S_dot<j>(f[j]);
+    if constexpr (p >= 0) {
+      T t[6];
+      xform_T<j>(tr[j], f[j], t);
+      sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+    }
+  });
+  if (c_out != nullptr && !isqd && slot < nvalid) {
+    sfor<0, N>([&](auto J) { c_out[b * N + decltype(J)::value] = c[decltype(J)::value]; });
+  }
+
+  // ---- LDS accumulator tile: layout == HBM layout of dc_du for this block's configurations ----
+  T* acc = tile + slot * GRAD_TS + (isqd ? N : 0);   // acc[i * 2N + c]
+  // entries (i, c) with unrelated bodies are structurally zero and never touched below
+  sfor<0, N>([&](auto I) {
+    sfor<0, N>([&](auto C) {
+      constexpr int i = decltype(I)::value, cc = decltype(C)::value;
+      if constexpr (!related(i, cc)) acc[i * GRAD_ROW + cc] = T(0);
+    });
+  });
+
+  // ---- forward gradient sweep (:1139-1185, :1210-1252 fused; backward passes folded in) -------
+  // Column slot s of body j = its ancestor-or-self at depth s.  dv/da[j][s] are this lane's
+  // derivative columns (dq columns on even lanes, dqd columns on odd lanes).
+  T dv[N][MAXDEPTH][6], da[N][MAXDEPTH][6];
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    constexpr int d = DEPTH[j];
+    const T qdj = qdv[j];
+    // inherited columns: dv = X dv_p ; da = X da_p + qd_j crm(dv) S           (:1158,:1163,:1170)
+    sfor<0, d>([&](auto Sx) {
+      constexpr int s = decltype(Sx)::value;
+      xform<j>(tr[j], dv[p][s], dv[j][s]);
+      xform<j>(tr[j], da[p][s], da[j][s]);
+      add_mxS<j>(dv[j][s], qdj, da[j][s]);
+    });
+    // own column: dq:  dv = crm(X v_p) S (0 at a root, :1157-1159);  da = qd crm(dv) S + crm(X a_p) S (:1170-1175)
+    //             dqd: dv = S (:1231);                                da = qd crm(S) S (= 0) + crm(v_j) S (:1243)
+    {
+      T sdq[6], sS[6], e1[6], e2[6];
+      mxS<j>(xv[j], T(1), sdq);
+      sfor<0, 6>([&](auto R) { sS[decltype(R)::value] = T(0); });
+      add_S<j>(T(1), sS);
+      mxS<j>(xa[j], T(1), e1);
+      mxS<j>(v[j], T(1), e2);
+      sfor<0, 6>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        dv[j][d][r] = sel(isqd, sS[r], sdq[r]);
+        da[j][d][r] = sel(isqd, e2[r], e1[r]);
+      });
+      add_mxS<j>(dv[j][d], qdj, da[j][d]);
+    }
+    // df = I da + crf(dv) (I v) + crf(v) (I dv)                               (:1179-1185)
+    T Iv[6];
+    cmatvec<MatI, j>(v[j], Iv);
+    T df[d + 1][6], phi[d + 1][6];
+    sfor<0, d + 1>([&](auto Sx) {
+      constexpr int s = decltype(Sx)::value;
+      T Idv[6];
+      cmatvec<MatI, j>(da[j][s], df[s]);
+      cmatvec<MatI, j>(dv[j][s], Idv);
+      fxv<true>(dv[j][s], Iv, df[s]);
+      fxv<true>(v[j], Idv, df[s]);
+      sfor<0, 6>([&](auto R) { phi[s][decltype(R)::value] = from_odd_lane(dv[j][s][decltype(R)::value]); });
+    });
+    // extra dq term of the backward pass (:1292-1294): column j gains X_j^T fxS(S_j, f_j) at the
+    // parent, i.e. rows i that are STRICT ancestors see  Phi[i, j]^T (-crm(f_j) S_j).
+    T dfx[6];
+    {
+      T w[6];
+      mxS<j>(f[j], T(-1), w);
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dfx[r] = df[d][r] + sel(isqd, T(0), w[r]); });
+    }
+    // dc[i, c] += Phi[i]^T df[c] for all ancestor-or-self pairs of j
+    sfor<0, d + 1>([&](auto Si) {
+      constexpr int si = decltype(Si)::value;
+      constexpr int row = anc_at(j, si);
+      sfor<0, d + 1>([&](auto Sc) {
+        constexpr int sc = decltype(Sc)::value;
+        constexpr int col = anc_at(j, sc);
+        T val;
+        if constexpr (sc == d && si < d) val = dot6(phi[si], dfx);
+        else val = dot6(phi[si], df[sc]);
+        if constexpr (si == d || sc == d) acc[row * GRAD_ROW + col] = val;   // first touch of (row, col)
+        else lds_add(&acc[row * GRAD_ROW + col], val);
+      });
+    });
+  });
+  if (use_damping && isqd) {  // :1336-1341
+    sfor<0, N>([&](auto I) { constexpr int i = decltype(I)::value; lds_add(&acc[i * GRAD_ROW + i], T(DAMPING[i])); });
+  }
+  __syncthreads();
+  // ---- coalesced write-out of the tile ---------------------------------------------------------
+  T* gdst = dcdu + cfg0 * GRAD_TILE;
+  const int total = nvalid * GRAD_TILE;
+#pragma unroll 4
+  for (int g = lane; g < total; g += NT) {
+    int cfg = g / GRAD_TILE;
+    gdst[g] = tile[g + cfg * (GRAD_TS - GRAD_TILE)];
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// minv: q -> Minv [B, n, n]                                                    (:630-806)
+//
+// Two launches.  Phase A (one configuration per lane) runs the articulated-inertia recursion
+// of the backward pass (:697-700, :728-733) -- the only part that is serial per configuration --
+// and leaves {U_i, 1/D_i, sin q_i, cos q_i} per body in a workspace laid out [body][config][12].
+// Phase B gives every COLUMN of Minv / F its own lane (columns are independent: :702-726,
+// :771-776): a column's F vector climbs its unique root path in the backward sweep and the
+// forward sweep recomputes F per body, so the reference's (n, 6, n) F tensor never exists.
+// ---------------------------------------------------------------------------------------------
+constexpr int MINV_WS = 12;   // scalars per (body, configuration) in the workspace
+
+template <class T>
+struct BodyCfg {
+  T U[6];
+  T Dinv;   // 1 / D   (the reference's `Dinv` array holds D itself, :698)
+  T s, c;
+};
+
+template <class T>
+RBD_DEV void ws_store(T* ws, long long B, int i, long long b, const BodyCfg<T>& bc) {
+  constexpr int VE = 16 / sizeof(T);
+  typedef T V __attribute__((ext_vector_type(VE)));
+  V* dst = reinterpret_cast<V*>(ws + ((long long)i * B + b) * MINV_WS);
+  const T flat[MINV_WS] = {bc.U[0], bc.U[1], bc.U[2], bc.U[3], bc.U[4], bc.U[5], bc.Dinv, bc.s, bc.c, T(0), T(0), T(0)};
+  sfor<0, MINV_WS / VE>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    V x;
+    sfor<0, VE>([&](auto E) { x[decltype(E)::value] = flat[k * VE + decltype(E)::value]; });
+    dst[k] = x;
+  });
+}
+template <class T>
+RBD_DEV BodyCfg<T> ws_load(const T* ws, long long B, int i, long long b) {
+  constexpr int VE = 16 / sizeof(T);
+  typedef T V __attribute__((ext_vector_type(VE)));
+  const V* src = reinterpret_cast<const V*>(ws + ((long long)i * B + b) * MINV_WS);
+  T flat[MINV_WS];
+  sfor<0, MINV_WS / VE>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    const V x = src[k];
+    sfor<0, VE>([&](auto E) { flat[k * VE + decltype(E)::value] = x[decltype(E)::value]; });
+  });
+  BodyCfg<T> bc;
+  sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = flat[decltype(R)::value]; });
+  bc.Dinv = flat[6]; bc.s = flat[7]; bc.c = flat[8];
+  return bc;
+}
+
+constexpr int s_index(int i) { return (JTYPE[i] == 0 ? 0 : 3) + AXIS[i]; }
+
+template <class T>
+__global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, long long B, T* __restrict__ ws) {
+  const int lane = threadIdx.x;
+  const long long b0 = (long long)blockIdx.x * 64 + lane;
+  const bool valid = b0 < B;
+  const long long b = valid ? b0 : B - 1;
+  JTrig<T> tr[N];
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(q[b * N + j]); });
+  T IA[N][6][6];
+  sfor<0, N>([&](auto J) {
+    sfor<0, 6>([&](auto R) {
+      sfor<0, 6>([&](auto C) {
+        constexpr int j = decltype(J)::value, r = decltype(R)::value, c = decltype(C)::value;
+        IA[j][r][c] = T(IM[j][r * 6 + c]);
+      });
+    });
+  });
+  sfor_down<0, N>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int p = PARENT[i];
+    constexpr int si = s_index(i);
+    BodyCfg<T> bc;
+    sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = IA[i][decltype(R)::value][si]; });   // U = IA S   (:697)
+    bc.Dinv = T(1) / bc.U[si];                                                                 // D = S^T U (:698,:700)
+    bc.s = tr[i].s; bc.c = tr[i].c;
+    if (valid) ws_store(ws, B, i, b, bc);
+    if constexpr (p >= 0) {
+      // Ia = IA - U U^T / D  (:728-731);  IA_p += X^T Ia X  (:732-733)
+      T A[6][6];   // A = X^T Ia, built column by column
+      sfor<0, 6>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        T col[6], y[6];
+        const T uc = bc.U[c] * bc.Dinv;
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-bc.U[r], uc, IA[i][r][c]); });
+        xform_T<i>(tr[i], col, y);
+        sfor<0, 6>([&](auto R) { A[decltype(R)::value][c] = y[decltype(R)::value]; });
+      });
+      sfor<0, 6>([&](auto R) {   // (A X)[r][:] = X^T A[r][:]^T
+        constexpr int r = decltype(R)::value;
+        T y[6];
+        xform_T<i>(tr[i], A[r], y);
+        sfor<0, 6>([&](auto C) { IA[p][r][decltype(C)::value] += y[decltype(C)::value]; });
+      });
+    }
+  });
+}
+
+constexpr int MINV_LC = (N <= 8) ? 8 : (N <= 16) ? 16 : (N <= 32) ? 32 : 64;   // lanes per configuration
+constexpr int MINV_CPB = 64 / MINV_LC;                                         // configurations per wave
+constexpr int MINV_TS = (N * N) | 1;                                           // LDS tile stride (odd)
+constexpr unsigned long long subtree_mask(int i) {
+  unsigned long long m = 0;
+  for (int j = 0; j < N; ++j) m |= is_anc_or_self(i, j) ? (1ull << j) : 0ull;
+  return m;
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
+                                                       T* __restrict__ Minv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const int j = lane % MINV_LC;          // this lane's column
+  const int slot = lane / MINV_LC;
+  const long long cfg0 = (long long)blockIdx.x * MINV_CPB;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < MINV_CPB ? (int)rem : MINV_CPB;
+  const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
+
+  T mcol[N];
+  T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  // ---- backward sweep (:665-726), column j -----------------------------------------------------
+  sfor_down<0, N>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int p = PARENT[i];
+    constexpr unsigned long long mask = subtree_mask(i);
+    const BodyCfg<T> bc = ws_load(ws, B, i, b);
+    const bool insub = ((mask >> j) & 1ull) != 0;
+    T m = sel(j == i, bc.Dinv, -(bc.Dinv * S_dot<i>(Fj)));         // :700, :702-708
+    m = sel(insub, m, T(0));
+    mcol[i] = m;
+    if constexpr (p >= 0) {
+      T t[6], y[6];
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(bc.U[r], m, Fj[r]); });   // :721-723
+      const JTrig<T> g{bc.s, bc.c};
+      xform_T<i>(g, t, y);                                                                                  // :724-726
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fj[r] = sel(insub, y[r], Fj[r]); });
+    }
+  });
+  // ---- forward sweep (:760-781), column j ------------------------------------------------------
+  T Ff[N][6];
+  sfor<0, N>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int p = PARENT[i];
+    constexpr int si = s_index(i);
+    if constexpr (p < 0) {
+      sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
+      Ff[i][si] = mcol[i];                                                                        // :781
+    } else {
+      const BodyCfg<T> bc = ws_load(ws, B, i, b);
+      const JTrig<T> g{bc.s, bc.c};
+      xform<i>(g, Ff[p], Ff[i]);
+      const T m = fma_(-bc.Dinv, dot6(bc.U, Ff[i]), mcol[i]);                                     // :771-773
+      mcol[i] = m;
+      Ff[i][si] += m;                                                                             // :774-776
+    }
+  });
+  // ---- symmetrise (:799-804) through LDS, then stream the tile out ------------------------------
+  T* myt = tile + slot * MINV_TS;
+  if (j < N) {
+    sfor<0, N>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if (i <= j) myt[i * N + j] = mcol[i];
+      if (i < j) myt[j * N + i] = sel(dense != 0, mcol[i], T(0));
+    });
+  }
+  __syncthreads();
+  T* gdst = Minv + cfg0 * (N * N);
+  const int total = nvalid * N * N;
+#pragma unroll 4
+  for (int g = lane; g < total; g += 64) {
+    int cfg = g / (N * N);
+    gdst[g] = tile[g + cfg * (MINV_TS - N * N)];
+  }
+}
+
+}  // namespace rbdk
+
+// =============================================================================================
+// C-ABI (include/rbd_hip.h)
+// =============================================================================================
+#include "../../include/rbd_hip.h"
+#include <cstdio>
+#include <cstring>
+
+// The library is built from several translation units of this one file (rbdreference_amd/build.py
+// compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
+// _MINV_F32, _MINV_F64; no RBD_TU_* macro at all = everything in one unit.
+#if !defined(RBD_TU_COMMON) && !defined(RBD_TU_RNEA_F32) && !defined(RBD_TU_RNEA_F64) && \
+    !defined(RBD_TU_GRAD_F32) && !defined(RBD_TU_GRAD_F64) && !defined(RBD_TU_MINV_F32) && \
+    !defined(RBD_TU_MINV_F64)
+#define RBD_TU_COMMON 1
+#define RBD_TU_RNEA_F32 1
+#define RBD_TU_RNEA_F64 1
+#define RBD_TU_GRAD_F32 1
+#define RBD_TU_GRAD_F64 1
+#define RBD_TU_MINV_F32 1
+#define RBD_TU_MINV_F64 1
+#endif
+
+// thread-local message buffer behind rbd_last_error(); one instance, owned by the COMMON unit
+extern "C" __attribute__((visibility("hidden"))) char* rbd_err_buf(void);
+#ifdef RBD_TU_COMMON
+extern "C" char* rbd_err_buf(void) {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+#endif
+constexpr size_t RBD_ERR_LEN = 512;
+
+namespace {
+int fail(int code, const char* msg) {
+  std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s", msg);
+  return code;
+}
+int hip_fail(hipError_t e, const char* where) {
+  std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: %s", where, hipGetErrorString(e));
+  return (int)e > 0 ? (int)e : 1;
+}
+
+template <class K>
+int ensure_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  }
+  return 0;
+}
+
+template <class T>
+int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f,
+                void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !c) return fail(RBD_ERR_ARG, "rbd_rnea: q, qd and c must be non-null");
+  const bool vaf = v || a || f;
+  if (vaf && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea: v, a, f must be all null or all non-null");
+  const int64_t blocks = (B + 63) / 64;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea: B too large");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(T) * 64 * (size_t)odd_pad<6 * N>();
+  const size_t lds_c = sizeof(T) * 64 * (size_t)odd_pad<N>();
+  int rc;
+#define RBD_LAUNCH_RNEA(HQ, VAF, LDS)                                                              \
+  do {                                                                                             \
+    auto k = rnea_kernel<T, HQ, VAF>;                                                              \
+    if ((rc = ensure_lds(k, LDS)) != 0) return rc;                                                 \
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), LDS, s, q, qd, qdd, gravity,           \
+                       (long long)B, c, v, a, f);                                                  \
+  } while (0)
+  if (qdd) { if (vaf) RBD_LAUNCH_RNEA(true, true, lds); else RBD_LAUNCH_RNEA(true, false, lds_c); }
+  else     { if (vaf) RBD_LAUNCH_RNEA(false, true, lds); else RBD_LAUNCH_RNEA(false, false, lds_c); }
+#undef RBD_LAUNCH_RNEA
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_rnea launch");
+  return 0;
+}
+
+template <class T>
+int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                     T* c, T* dc_du, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
+  constexpr int CFGS = grad_cfgs<T>();
+  const int64_t blocks = (B + CFGS - 1) / CFGS;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+  const size_t lds = sizeof(T) * (size_t)CFGS * GRAD_TS;
+  if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (qdd) {
+    auto k = rnea_grad_kernel<T, true>;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(2 * CFGS), lds, s, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+  } else {
+    auto k = rnea_grad_kernel<T, false>;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(2 * CFGS), lds, s, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
+  return 0;
+}
+
+template <class T>
+int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspace, size_t wsb, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
+  if (B == 0) return 0;
+  if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  const size_t need = (size_t)B * N * MINV_WS * sizeof(T);
+  if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
+  const int64_t blocksA = (B + 63) / 64, blocksB = (B + MINV_CPB - 1) / MINV_CPB;
+  if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
+  hipStream_t s = (hipStream_t)stream;
+  T* ws = reinterpret_cast<T*>(workspace);
+  hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_minv phase A launch");
+  const size_t lds = sizeof(T) * (size_t)MINV_CPB * MINV_TS;
+  auto k = minv_cols_kernel<T>;
+  int rc;
+  if ((rc = ensure_lds(k, lds)) != 0) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocksB), dim3(64), lds, s, (const T*)ws, (long long)B, output_dense, Minv);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_minv phase B launch");
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+#ifdef RBD_TU_COMMON
+int rbd_abi_version(void) { return RBD_ABI_VERSION; }
+const char* rbd_last_error(void) { return rbd_err_buf(); }
+
+int rbd_model_info(rbd_model_info_t* out) {
+  if (!out) return fail(RBD_ERR_ARG, "rbd_model_info: out is null");
+  std::memset(out, 0, sizeof(*out));
+  out->abi_version = RBD_ABI_VERSION;
+  out->n = rbdm::N;
+  out->max_depth = rbdm::MAXDEPTH;
+  out->hash = RBD_MODEL_HASH;
+  std::snprintf(out->name, sizeof(out->name), "%s", RBD_MODEL_NAME);
+  for (int i = 0; i < rbdm::N && i < RBD_MAX_BODIES; ++i) {
+    out->parent[i] = rbdm::PARENT[i];
+    out->joint_type[i] = rbdm::JTYPE[i];
+    out->joint_axis[i] = rbdm::AXIS[i];
+  }
+  return 0;
+}
+size_t rbd_minv_workspace_bytes(int64_t B, int elem_size) {
+  if (B <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
+  return (size_t)B * rbdm::N * rbdk::MINV_WS * (size_t)elem_size;
+}
+#endif
+#ifdef RBD_TU_RNEA_F32
+int rbd_rnea_f32(const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
+                 float* c, float* v, float* a, float* f, void* stream) {
+  return rnea_launch<float>(q, qd, qdd, gravity, B, c, v, a, f, stream);
+}
+#endif
+#ifdef RBD_TU_RNEA_F64
+int rbd_rnea_f64(const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
+                 double* c, double* v, double* a, double* f, void* stream) {
+  return rnea_launch<double>(q, qd, qdd, gravity, B, c, v, a, f, stream);
+}
+#endif
+#ifdef RBD_TU_GRAD_F32
+int rbd_rnea_grad_f32(const float* q, const float* qd, const float* qdd, float gravity,
+                      int use_damping, int64_t B, float* c, float* dc_du, void* stream) {
+  return rnea_grad_launch<float>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+}
+#endif
+#ifdef RBD_TU_GRAD_F64
+int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, double gravity,
+                      int use_damping, int64_t B, double* c, double* dc_du, void* stream) {
+  return rnea_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+}
+#endif
+#ifdef RBD_TU_MINV_F32
+int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  return minv_launch<float>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+}
+#endif
+#ifdef RBD_TU_MINV_F64
+int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  return minv_launch<double>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+}
+#endif
+
+}  // extern "C"

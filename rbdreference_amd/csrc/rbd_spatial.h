@@ -1,0 +1,268 @@
+// rbd_spatial.h -- compile-time-specialised spatial algebra for one robot (gfx950 device code).
+//
+// Included by rbd_kernels.hip AFTER the generated model header (namespace rbdm: N, PARENT[],
+// DEPTH[], JTYPE[], AXIS[], XT[][36], IM[][36], DAMPING[]).  Every loop over bodies, matrix rows
+// or columns is a template-unrolled `sfor`, so that
+//   * the kinematic tree is resolved at compile time (no runtime parent[] walks, all per-body state
+//     is statically indexed and lives in VGPRs),
+//   * structural zeros / +-1 of X_tree and of the spatial inertias cost nothing,
+//   * the model constants become literal / SGPR operands of the FMAs.
+// This replaces the reference's getter calls and dense 6x6 numpy products
+// (/root/reference/RBDReference.py:570-596) and its sparse-S special cases mx1..mx6 (:77-147).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
+
+namespace rbdk {
+using namespace rbdm;
+
+#define RBD_DEV __device__ __forceinline__
+
+template <int I, int E, class F>
+RBD_DEV void sfor(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, E>(static_cast<F&&>(f));
+  }
+}
+// descending: E-1 ... I
+template <int I, int E, class F>
+RBD_DEV void sfor_down(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, E - 1>{});
+    sfor_down<I, E - 1>(static_cast<F&&>(f));
+  }
+}
+
+// by-value select: `c ? x[i] : y[i]` on two lvalues is an lvalue conditional, which clang lowers to a
+// select of ADDRESSES and thereby forces the arrays into scratch memory.
+template <class T>
+RBD_DEV T sel(bool c, T a, T b) { return c ? a : b; }
+
+RBD_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RBD_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- compile-time tree queries ---------------------------------------------------------------
+constexpr bool is_anc_or_self(int a, int j) {
+  while (j != -1) {
+    if (j == a) return true;
+    j = PARENT[j];
+  }
+  return false;
+}
+constexpr bool related(int i, int j) { return is_anc_or_self(i, j) || is_anc_or_self(j, i); }
+// ancestor-or-self of body j that sits at depth d (d <= DEPTH[j])
+constexpr int anc_at(int j, int d) {
+  while (DEPTH[j] > d) j = PARENT[j];
+  return j;
+}
+constexpr int subtree_size(int i) {
+  int k = 0;
+  for (int j = 0; j < N; ++j) k += is_anc_or_self(i, j) ? 1 : 0;
+  return k;
+}
+constexpr bool has_child(int i) {
+  for (int j = 0; j < N; ++j)
+    if (PARENT[j] == i) return true;
+  return false;
+}
+
+// ---- constant 6x6 operators (X_tree, X_tree^T, I) ---------------------------------------------
+struct MatXT {
+  static constexpr double at(int j, int r, int c) { return XT[j][r * 6 + c]; }
+};
+struct MatXTt {
+  static constexpr double at(int j, int r, int c) { return XT[j][c * 6 + r]; }
+};
+struct MatI {
+  static constexpr double at(int j, int r, int c) { return IM[j][r * 6 + c]; }
+};
+template <class M, int J>
+constexpr int nz_before(int r, int c) {
+  int k = 0;
+  for (int i = 0; i < c; ++i) k += (M::at(J, r, i) != 0.0) ? 1 : 0;
+  return k;
+}
+
+// y = M_J x with compile-time sparsity; y must not alias x.
+template <class M, int J, class T>
+RBD_DEV void cmatvec(const T (&x)[6], T (&y)[6]) {
+  sfor<0, 6>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    T acc = T(0);
+    sfor<0, 6>([&](auto C) {
+      constexpr int c = decltype(C)::value;
+      constexpr double k = M::at(J, r, c);
+      if constexpr (k != 0.0) {
+        if constexpr (nz_before<M, J>(r, c) == 0) {
+          if constexpr (k == 1.0) acc = x[c];
+          else if constexpr (k == -1.0) acc = -x[c];
+          else acc = T(k) * x[c];
+        } else {
+          if constexpr (k == 1.0) acc = acc + x[c];
+          else if constexpr (k == -1.0) acc = acc - x[c];
+          else acc = fma_(T(k), x[c], acc);
+        }
+      }
+    });
+    y[r] = acc;
+  });
+}
+
+// Per-joint trig: revolute (s, c) = (sin q, cos q); prismatic (s, c) = (q, unused).
+template <class T>
+struct JTrig {
+  T s, c;
+};
+
+// y = X_J(q) t   (motion vectors, parent -> child); may alias.
+template <int J, class T>
+RBD_DEV void joint_fwd(const JTrig<T>& g, const T (&t)[6], T (&y)[6]) {
+  constexpr int k = AXIS[J], a = (k + 1) % 3, b = (k + 2) % 3;
+  if constexpr (JTYPE[J] == 0) {
+    T ya = fma_(g.c, t[a], g.s * t[b]), yb = fma_(g.c, t[b], -(g.s * t[a]));
+    T la = fma_(g.c, t[3 + a], g.s * t[3 + b]), lb = fma_(g.c, t[3 + b], -(g.s * t[3 + a]));
+    y[a] = ya; y[b] = yb; y[k] = t[k];
+    y[3 + a] = la; y[3 + b] = lb; y[3 + k] = t[3 + k];
+  } else {
+    T la = fma_(g.s, t[b], t[3 + a]), lb = fma_(-g.s, t[a], t[3 + b]);
+    y[0] = t[0]; y[1] = t[1]; y[2] = t[2];
+    y[3 + a] = la; y[3 + b] = lb; y[3 + k] = t[3 + k];
+  }
+}
+// y = X_J(q)^T t  (forces, child -> parent); may alias.
+template <int J, class T>
+RBD_DEV void joint_bwd(const JTrig<T>& g, const T (&t)[6], T (&y)[6]) {
+  constexpr int k = AXIS[J], a = (k + 1) % 3, b = (k + 2) % 3;
+  if constexpr (JTYPE[J] == 0) {
+    T ya = fma_(g.c, t[a], -(g.s * t[b])), yb = fma_(g.c, t[b], g.s * t[a]);
+    T la = fma_(g.c, t[3 + a], -(g.s * t[3 + b])), lb = fma_(g.c, t[3 + b], g.s * t[3 + a]);
+    y[a] = ya; y[b] = yb; y[k] = t[k];
+    y[3 + a] = la; y[3 + b] = lb; y[3 + k] = t[3 + k];
+  } else {
+    T ya = fma_(-g.s, t[3 + b], t[a]), yb = fma_(g.s, t[3 + a], t[b]);
+    y[a] = ya; y[b] = yb; y[k] = t[k];
+    y[3] = t[3]; y[4] = t[4]; y[5] = t[5];
+  }
+}
+// y = X_J(q) x = X_joint(q) (X_tree x)
+template <int J, class T>
+RBD_DEV void xform(const JTrig<T>& g, const T (&x)[6], T (&y)[6]) {
+  T t[6];
+  cmatvec<MatXT, J>(x, t);
+  joint_fwd<J>(g, t, y);
+}
+// y = X_J(q)^T x = X_tree^T (X_joint(q)^T x)
+template <int J, class T>
+RBD_DEV void xform_T(const JTrig<T>& g, const T (&x)[6], T (&y)[6]) {
+  T t[6];
+  joint_bwd<J>(g, x, t);
+  cmatvec<MatXTt, J>(t, y);
+}
+
+// out = alpha * crm(v) S_J  (mxS / _mxS, RBDReference.py:56-75); structural zeros are written as 0.
+template <int J, class T>
+RBD_DEV void mxS(const T (&v)[6], T alpha, T (&out)[6]) {
+  constexpr int k = AXIS[J], a = (k + 1) % 3, b = (k + 2) % 3;
+  sfor<0, 6>([&](auto R) { out[decltype(R)::value] = T(0); });
+  if constexpr (JTYPE[J] == 0) {
+    out[a] = alpha * v[b];
+    out[b] = -(alpha * v[a]);
+    out[3 + a] = alpha * v[3 + b];
+    out[3 + b] = -(alpha * v[3 + a]);
+  } else {
+    out[3 + a] = alpha * v[b];
+    out[3 + b] = -(alpha * v[a]);
+  }
+}
+// acc += alpha * crm(v) S_J   (touches only the structurally non-zero components)
+template <int J, class T>
+RBD_DEV void add_mxS(const T (&v)[6], T alpha, T (&acc)[6]) {
+  constexpr int k = AXIS[J], a = (k + 1) % 3, b = (k + 2) % 3;
+  if constexpr (JTYPE[J] == 0) {
+    acc[a] = fma_(alpha, v[b], acc[a]);
+    acc[b] = fma_(-alpha, v[a], acc[b]);
+    acc[3 + a] = fma_(alpha, v[3 + b], acc[3 + a]);
+    acc[3 + b] = fma_(-alpha, v[3 + a], acc[3 + b]);
+  } else {
+    acc[3 + a] = fma_(alpha, v[b], acc[3 + a]);
+    acc[3 + b] = fma_(-alpha, v[a], acc[3 + b]);
+  }
+}
+// S_J^T f  (component pick) and  x += alpha * S_J
+template <int J, class T>
+RBD_DEV T S_dot(const T (&f)[6]) {
+  return f[(JTYPE[J] == 0 ? 0 : 3) + AXIS[J]];
+}
+template <int J, class T>
+RBD_DEV void add_S(T alpha, T (&x)[6]) {
+  x[(JTYPE[J] == 0 ? 0 : 3) + AXIS[J]] += alpha;
+}
+
+// r (+)= crf(v) b   (fxv, RBDReference.py:149-164)
+template <bool ACC, class T>
+RBD_DEV void fxv(const T (&v)[6], const T (&b)[6], T (&r)[6]) {
+  T r0 = fma_(v[1], b[2], fma_(-v[2], b[1], fma_(v[4], b[5], -(v[5] * b[4]))));
+  T r1 = fma_(v[2], b[0], fma_(-v[0], b[2], fma_(v[5], b[3], -(v[3] * b[5]))));
+  T r2 = fma_(v[0], b[1], fma_(-v[1], b[0], fma_(v[3], b[4], -(v[4] * b[3]))));
+  T r3 = fma_(v[1], b[5], -(v[2] * b[4]));
+  T r4 = fma_(v[2], b[3], -(v[0] * b[5]));
+  T r5 = fma_(v[0], b[4], -(v[1] * b[3]));
+  if constexpr (ACC) {
+    r[0] += r0; r[1] += r1; r[2] += r2; r[3] += r3; r[4] += r4; r[5] += r5;
+  } else {
+    r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4; r[5] = r5;
+  }
+}
+
+template <class T>
+RBD_DEV T dot6(const T (&x)[6], const T (&y)[6]) {
+  return fma_(x[5], y[5], fma_(x[4], y[4], fma_(x[3], y[3], fma_(x[2], y[2], fma_(x[1], y[1], x[0] * y[0])))));
+}
+
+RBD_DEV void sincos_(float q, float* s, float* c) { sincosf(q, s, c); }
+RBD_DEV void sincos_(double q, double* s, double* c) { sincos(q, s, c); }
+
+template <int J, class T>
+RBD_DEV JTrig<T> make_trig(T q) {
+  JTrig<T> g;
+  if constexpr (JTYPE[J] == 0) {
+    sincos_(q, &g.s, &g.c);
+  } else {
+    g.s = q;
+    g.c = T(0);
+  }
+  return g;
+}
+
+// One RNEA forward step for body J (RBDReference.py:569-596): given the parent's v, a produces
+// xv = X v_p, xa = X a_p (X a0 at a root), v_J, a_J and the local force f_J.
+template <int J, bool HAS_QDD, class T>
+RBD_DEV void rnea_fwd_body(const JTrig<T>& g, T qd, T qdd, T grav, const T (&vp)[6], const T (&ap)[6],
+                           T (&xv)[6], T (&xa)[6], T (&v)[6], T (&a)[6], T (&f)[6]) {
+  if constexpr (PARENT[J] < 0) {
+    // v_base = 0; a_base = [0,0,0,0,0,-GRAVITY]  (:565-566, :578)
+    sfor<0, 6>([&](auto R) { xv[decltype(R)::value] = T(0); });
+    T a0[6] = {T(0), T(0), T(0), T(0), T(0), -grav};
+    xform<J>(g, a0, xa);
+  } else {
+    xform<J>(g, vp, xv);
+    xform<J>(g, ap, xa);
+  }
+  sfor<0, 6>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    v[r] = xv[r];
+    a[r] = xa[r];
+  });
+  add_S<J>(qd, v);             // v += S qd              (:586-587)
+  add_mxS<J>(v, qd, a);        // a += crm(v) (S qd)     (:588)
+  if constexpr (HAS_QDD) add_S<J>(qdd, a);  // (:589-593)
+  T Iv[6], Ia[6];
+  cmatvec<MatI, J>(v, Iv);
+  cmatvec<MatI, J>(a, Ia);
+  sfor<0, 6>([&](auto R) { f[decltype(R)::value] = Ia[decltype(R)::value]; });
+  fxv<true>(v, Iv, f);         // f = I a + crf(v) I v   (:595-596)
+}
+
+}  // namespace rbdk

@@ -1,0 +1,220 @@
+"""GPU parity tests (run with ``-m gpu`` on a real MI355X).  Every call goes through the ctypes
+C-ABI into the per-robot HIP library; the CPU oracle and the golden vectors generated from the real
+reference are the checkers.  Tolerances (BASELINE.json north_star): per-row,
+per-tensor normwise relative error  max|x - ref| / max|ref|  <= 1e-5 in fp32, <= 1e-11 in fp64
+(element-wise relative error is meaningless in fp32: input rounding alone moves small entries by
+1e-3)."""
+import numpy as np
+import pytest
+
+from conftest import all_golden_names, load_golden, make_robot, rel_err_rows
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+TOL64 = 1e-11
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch
+
+
+_RBD = {}
+
+
+def rbd_for(name):
+    if name not in _RBD:
+        from rbdreference_amd import RBDReference
+        _RBD[name] = RBDReference(make_robot(name), build=False)   # prebuilt by __graft_entry__.build()
+    return _RBD[name]
+
+
+def dev_tensors(dtype, *arrs):
+    torch = _torch()
+    return [None if a is None else torch.tensor(a, device="cuda:0", dtype=dtype) for a in arrs]
+
+
+def check(name, got, want, tol):
+    got = got.double().cpu().numpy()
+    assert got.shape == want.shape, f"{name}: shape {got.shape} != {want.shape}"
+    assert np.all(np.isfinite(got)), f"{name}: non-finite values"
+    e = rel_err_rows(got, want)
+    assert e <= tol, f"{name}: worst-row normwise rel err {e:.3e} > {tol}"
+    return e
+
+
+@pytest.fixture(params=["float32", "float64"])
+def prec(request):
+    torch = _torch()
+    return (torch.float32, TOL32) if request.param == "float32" else (torch.float64, TOL64)
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_library_loaded_is_the_hip_one(name):
+    rbd = rbd_for(name)
+    assert rbd._lib.path.endswith(".so") and "_build" in rbd._lib.path
+    assert rbd._lib.info.n == rbd.n
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_rnea_vs_golden(name, prec):
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    c, v, a, f = rbd.rnea(q, qd, qdd)
+    check("c", c, g["c"], tol); check("v", v, g["fpass_v"], tol); check("a", a, g["fpass_a"], tol)
+    check("f (accumulated)", f, g["f_acc"], tol)
+    c0, _, _, _ = rbd.rnea(q, qd)                       # qdd=None
+    check("c_noqdd", c0, g["c_noqdd"], tol)
+    c1, v1, a1, f1 = rbd.rnea(q, qd, qdd, outputs="c")
+    assert v1 is None and f1 is None
+    check("c (c-only kernel)", c1, g["c"], tol)
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_rnea_grad_vs_golden(name, prec):
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    c, dc = rbd.rnea_grad(q, qd, qdd, return_c=True)
+    check("dc_du", dc, g["dc_du"], tol); check("c", c, g["c"], tol)
+    check("dc_du_damped", rbd.rnea_grad(q, qd, qdd, USE_VELOCITY_DAMPING=True), g["dc_du_damped"], tol)
+    check("dc_du_noqdd", rbd.rnea_grad(q, qd), g["dc_du_noqdd"], tol)
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_minv_vs_golden(name, prec):
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    (q,) = dev_tensors(dt, g["q"])
+    tol_m = tol * (10 if dt == _torch().float32 and rbd.n >= 30 else 1)
+    check("Minv_dense", rbd.minv(q), g["Minv_dense"], tol_m)
+    up = rbd.minv(q, output_dense=False)
+    want = np.triu(g["Minv_upper"])                    # reference leaves by-products below the diagonal
+    check("Minv_upper", up, want, tol_m)
+    assert float(up.double().cpu().numpy()[:, np.tril_indices(rbd.n, -1)[0], np.tril_indices(rbd.n, -1)[1]].__abs__().max(initial=0.0)) == 0.0
+
+
+@pytest.mark.parametrize("name", ["iiwa_like", "quadruped_like", "atlas_like"])
+@pytest.mark.parametrize("B", [1, 31, 33, 257, 1000])
+def test_batch_sizes_vs_oracle(name, B):
+    """Ragged batches (not multiples of the 32/64-configuration blocks) against the oracle."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    robot = make_robot(name); rbd = rbd_for(name); om = orc.model_from_robot(robot)
+    rng = np.random.default_rng(1000 + B)
+    n = rbd.n
+    q = rng.uniform(-np.pi, np.pi, (B, n)); qd = rng.uniform(-1, 1, (B, n)); qdd = rng.uniform(-1, 1, (B, n))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    c_ref, dc_ref = orc.rnea_grad(om, q, qd, qdd, return_c=True)
+    c, dc = rbd.rnea_grad(tq, tqd, tqdd, return_c=True)
+    check("dc_du", dc, dc_ref, TOL64); check("c", c, c_ref, TOL64)
+    cr, vr, ar, fr = orc.rnea(om, q, qd, qdd)
+    c2, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    check("c", c2, cr, TOL64); check("v", v, vr, TOL64); check("a", a, ar, TOL64); check("f", f, fr, TOL64)
+    check("minv", rbd.minv(tq), orc.minv(om, q), TOL64)
+    # fp32 on the same inputs
+    sq, sqd, sqdd = dev_tensors(torch.float32, q, qd, qdd)
+    check("dc_du f32", rbd.rnea_grad(sq, sqd, sqdd), dc_ref, TOL32)
+    check("minv f32", rbd.minv(sq), orc.minv(om, q), TOL32 * (10 if n >= 30 else 1))
+
+
+def test_rows_are_independent_of_the_batch():
+    """out[b] == the single-configuration call on row b (bit-exact: same lane arithmetic)."""
+    torch = _torch()
+    rbd = rbd_for("iiwa_like")
+    rng = np.random.default_rng(3)
+    q, qd, qdd = dev_tensors(torch.float32, rng.uniform(-3, 3, (200, 7)), rng.uniform(-1, 1, (200, 7)),
+                             rng.uniform(-1, 1, (200, 7)))
+    dc = rbd.rnea_grad(q, qd, qdd)
+    Mi = rbd.minv(q)
+    for b in (0, 1, 63, 64, 199):
+        assert torch.equal(rbd.rnea_grad(q[b], qd[b], qdd[b]), dc[b])
+        assert torch.equal(rbd.minv(q[b]), Mi[b])
+        assert rbd.rnea_grad(q[b], qd[b], qdd[b]).shape == (7, 14)
+
+
+def test_numpy_in_numpy_out_and_lists():
+    rbd = rbd_for("iiwa_like")
+    g = load_golden("iiwa_like")
+    dc = rbd.rnea_grad(g["q"][2], list(g["qd"][2]), g["qdd"][2])
+    assert isinstance(dc, np.ndarray) and dc.dtype == np.float64 and dc.shape == (7, 14)
+    assert rel_err_rows(dc[None], g["dc_du"][2:3]) < TOL64
+    c, v, a, f = rbd.rnea(g["q"], g["qd"], g["qdd"])
+    assert isinstance(f, np.ndarray) and rel_err_rows(f, g["f_acc"]) < TOL64
+    assert rel_err_rows(rbd.minv(g["q"]), g["Minv_dense"]) < TOL64
+
+
+def test_argument_errors():
+    torch = _torch()
+    rbd = rbd_for("iiwa_like")
+    q = torch.zeros((4, 7), device="cuda:0")
+    with pytest.raises(ValueError):
+        rbd.rnea(q, q[:, :6])
+    with pytest.raises(ValueError):
+        rbd.rnea(q, q[:3])
+    with pytest.raises(TypeError):
+        rbd.rnea(q, q.double())
+    with pytest.raises(RuntimeError):
+        rbd.rnea(q.cpu(), q.cpu())
+    with pytest.raises(TypeError):
+        rbd.rnea(q.half(), q.half())
+    # C-ABI argument validation: null output pointer
+    from rbdreference_amd._lib import RBD_ERR_ARG, RbdError
+    with pytest.raises(RbdError) as ei:
+        rbd._lib.check(rbd._lib.lib.rbd_rnea_grad_f32(q.data_ptr(), q.data_ptr(), None, -9.81, 0, 4, None, None, None))
+    assert ei.value.code == RBD_ERR_ARG
+    # B = 0 is a no-op
+    e = torch.zeros((0, 7), device="cuda:0")
+    assert rbd.rnea_grad(e, e, e).shape == (0, 7, 14)
+    assert rbd.minv(e).shape == (0, 7, 7)
+
+
+def test_noncontiguous_inputs_are_handled():
+    torch = _torch()
+    rbd = rbd_for("iiwa_like")
+    g = load_golden("iiwa_like")
+    big = torch.tensor(np.concatenate([g["q"], g["qd"], g["qdd"]], axis=1), device="cuda:0")   # [S, 21]
+    q, qd, qdd = big[:, 0:7], big[:, 7:14], big[:, 14:21]           # strided views
+    assert not q.is_contiguous()
+    check("dc_du", rbd.rnea_grad(q, qd, qdd), g["dc_du"], TOL64)
+
+
+@pytest.mark.parametrize("name,B", [("iiwa_like", 1 << 20), ("atlas_like", 16384), ("quadruped_like", 65536)])
+def test_full_size_properties(name, B):
+    """BASELINE.json sizes: size-independent properties + sampled rows against the oracle.
+       * rnea is affine in qdd:  c(q,qd,qdd) - c(q,qd,0) = H(q) qdd  and  Minv H = I
+       * dc_dqd of rnea_grad does not depend on qdd; dc_dq is affine in qdd
+       * sampled rows equal the oracle."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    robot = make_robot(name); rbd = rbd_for(name); om = orc.model_from_robot(robot)
+    n = rbd.n
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(B)
+    dt = torch.float32
+    q = (torch.rand((B, n), device="cuda:0", generator=gen, dtype=dt) * 2 - 1) * np.pi
+    qd = torch.rand((B, n), device="cuda:0", generator=gen, dtype=dt) * 2 - 1
+    qdd = torch.rand((B, n), device="cuda:0", generator=gen, dtype=dt) * 2 - 1
+    c, dc = rbd.rnea_grad(q, qd, qdd, return_c=True)
+    c0, dc0 = rbd.rnea_grad(q, qd, torch.zeros_like(qdd), return_c=True)
+    Mi = rbd.minv(q)
+    assert torch.isfinite(dc).all() and torch.isfinite(Mi).all()
+    # Minv (c - c0) = Minv H qdd = qdd
+    back = torch.einsum("bij,bj->bi", Mi.double(), (c - c0).double())
+    scale = qdd.abs().max().item()
+    assert (back - qdd.double()).abs().max().item() < (5e-4 if n < 30 else 5e-3) * scale
+    # dc_dqd independent of qdd
+    d = (dc[:, :, n:] - dc0[:, :, n:]).abs().amax(dim=(1, 2)) / dc0[:, :, n:].abs().amax(dim=(1, 2)).clamp_min(1e-30)
+    assert d.max().item() < 1e-5
+    # symmetric dense Minv
+    assert torch.equal(Mi, Mi.transpose(1, 2))
+    # sampled rows vs oracle
+    idx = np.unique(np.concatenate([[0, 1, 31, 32, 63, 64, B - 1], np.random.default_rng(0).integers(0, B, 249)]))
+    tidx = torch.tensor(idx, device="cuda:0")
+    qs, qds, qdds = (x[tidx].double().cpu().numpy() for x in (q, qd, qdd))
+    c_ref, dc_ref = orc.rnea_grad(om, qs, qds, qdds, return_c=True)
+    check("dc_du sample", dc[tidx], dc_ref, TOL32)
+    check("c sample", c[tidx], c_ref, TOL32)
+    check("minv sample", Mi[tidx], orc.minv(om, qs), TOL32 * (10 if n >= 30 else 1))
