@@ -1,0 +1,147 @@
+"""CPU-side tests (no GPU): packer validation, generated header, C-ABI library loading / symbol
+export / argument errors, and the 'no CPU fallback' contract of the Python API."""
+import ctypes
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, make_robot
+
+from rbdreference_amd import pack_robot, iiwa_like, quadruped_like, atlas_like, random_tree
+from rbdreference_amd.packer import emit_header
+from rbdreference_amd.robot import Link, Robot
+
+HAVE_HIPCC = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
+
+
+def test_pack_builtin_topologies():
+    m7, m12, m30 = pack_robot(iiwa_like()), pack_robot(quadruped_like()), pack_robot(atlas_like())
+    assert m7.parent == [-1, 0, 1, 2, 3, 4, 5] and m7.max_depth == 7
+    assert m12.parent == [-1, 0, 1, -1, 3, 4, -1, 6, 7, -1, 9, 10] and m12.max_depth == 3
+    assert m30.n == 30 and m30.max_depth == 10
+    assert m30.ancestors(10) == [0, 1, 2, 4, 5, 6, 7, 8, 9]
+    # iiwa joint frames are related by multiples of pi/2: X_tree entries are exactly 0 / +-1 / offsets
+    E = m7.Xtree[:, :3, :3]
+    assert set(np.unique(E)) <= {-1.0, 0.0, 1.0}
+    for m in (m7, m12, m30):
+        for i in range(m.n):
+            w = np.linalg.eigvalsh(m.I[i])
+            assert w.min() > 0, f"{m.name} body {i}: spatial inertia not positive definite"
+
+
+def test_hash_is_stable_and_sensitive():
+    a, b = pack_robot(iiwa_like()), pack_robot(iiwa_like())
+    assert a.hash == b.hash and len(a.hash) == 16
+    r = iiwa_like()
+    r._I[3] = r._I[3] * 1.0000001
+    assert pack_robot(r).hash != a.hash
+
+
+def test_packer_rejects_unsupported_robots():
+    r = iiwa_like(); r.floating_base = True
+    with pytest.raises(NotImplementedError):
+        pack_robot(r)
+    r = iiwa_like(); r._S[2] = np.array([0.6, 0.8, 0, 0, 0, 0.0])
+    with pytest.raises(ValueError, match="coordinate axis"):
+        pack_robot(r)
+    r = iiwa_like(); f0 = r._Xfunc[1]; r._Xfunc[1] = lambda q: f0(2 * q)      # not X_J(q) X(0)
+    with pytest.raises(ValueError, match="unsupported joint convention"):
+        pack_robot(r)
+    r = iiwa_like(); r._I[0][0, 1] += 0.01                                     # asymmetric inertia
+    with pytest.raises(ValueError, match="symmetric"):
+        pack_robot(r)
+    with pytest.raises(ValueError):
+        Robot("bad", [Link("a", 0, 2, (0, 0, 0))])                             # parent must precede
+
+
+def test_header_is_bit_exact():
+    m = pack_robot(random_tree([-1, 0, 0, 2], seed=3))
+    h = emit_header(m)
+    assert f"constexpr int N = {m.n};" in h and f"0x{m.hash}ULL" in h
+    # hex-float literals round-trip exactly
+    row = h.split("constexpr double IM[N][36] = {")[1].split("};")[0].strip().splitlines()[0]
+    vals = [float.fromhex(t) if "x" in t else float(t) for t in row.strip(" {},").split(", ")]
+    assert np.array_equal(np.array(vals), m.I[0].reshape(-1))
+
+
+def _prebuilt(name):
+    from rbdreference_amd.build import lib_path
+    return lib_path(pack_robot(make_robot(name)))
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc not available")
+def test_capi_library_builds_loads_and_exports_every_symbol():
+    """Cross-compiles the small prismatic test robot if its library is stale (about a minute)."""
+    from rbdreference_amd._lib import EXPORTED_SYMBOLS, RbdLibrary, RbdModelInfo
+    robot = make_robot("random_prismatic_n6")
+    m = pack_robot(robot)
+    lib = RbdLibrary(m, build=True)
+    # every function include/rbd_hip.h declares is exported
+    hdr = open(os.path.join(ROOT, "include", "rbd_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\b(rbd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(EXPORTED_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib.lib, s), s
+    info = RbdModelInfo()
+    assert lib.lib.rbd_model_info(ctypes.byref(info)) == 0
+    assert info.n == 6 and list(info.parent[:6]) == m.parent and f"{info.hash:016x}" == m.hash
+    assert list(info.joint_type[:6]) == m.jtype and list(info.joint_axis[:6]) == m.axis
+    assert info.name.decode() == "random_prismatic_n6"
+    # argument errors are reported before anything touches a GPU
+    L = lib.lib
+    assert L.rbd_rnea_f32(None, None, None, -9.81, 4, None, None, None, None, None) == -1
+    assert b"non-null" in L.rbd_last_error()
+    assert L.rbd_rnea_grad_f64(1, 1, None, -9.81, 0, -5, None, 1, None) == -1
+    assert L.rbd_minv_f32(1, 4, 1, 1, None, 0, None) == -3
+    assert L.rbd_minv_workspace_bytes(10, 4) == 10 * 6 * 12 * 4
+    assert L.rbd_minv_workspace_bytes(10, 2) == 0
+    assert L.rbd_rnea_f32(None, None, None, -9.81, 0, None, None, None, None, None) == 0   # B = 0: no-op
+    assert L.rbd_abi_version() == 1
+
+
+def test_every_prebuilt_library_matches_its_robot():
+    """Libraries present in-tree (they travel to the GPU box) must be the ones for today's robots."""
+    from rbdreference_amd._lib import RbdLibrary
+    found = 0
+    for name in ("iiwa_like", "quadruped_like", "atlas_like", "random_tree_n9", "random_prismatic_n6"):
+        if os.path.exists(_prebuilt(name)):
+            RbdLibrary(pack_robot(make_robot(name)), build=False)     # raises on any mismatch
+            found += 1
+    if HAVE_HIPCC:
+        assert found >= 1
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import rbdreference_amd.build as b
+    from rbdreference_amd._lib import RbdLibrary
+    monkeypatch.setattr(b, "BUILD_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="no CPU fallback"):
+        RbdLibrary(pack_robot(random_tree([-1, 0], seed=99)), build=False)
+
+
+def test_api_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    if not os.path.exists(_prebuilt("iiwa_like")):
+        pytest.skip("iiwa library not built")
+    from rbdreference_amd import RBDReference
+    rbd = RBDReference(iiwa_like(), build=False)
+    q = np.zeros(7)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rbd.rnea(q, q, q)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rbd.minv(torch.zeros(3, 7))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "rbdreference_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "/root/reference" not in txt or f.endswith((".py", ".hip", ".h")), f
