@@ -23,6 +23,7 @@ ARCH = "gfx950"
 
 HIPCC_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-fno-slp-vectorize",         # packed-f32 pairs need aligned VGPR tuples: +70 VGPRs and scratch spills here
     "-fno-signed-zeros",          # lets structural zeros fold; the sign of a zero is never observable here
     "-munsafe-fp-atomics",        # LDS float adds lower to ds_add_f32 / ds_add_f64, never CAS loops
     "-Wno-unused-value",
@@ -66,12 +67,14 @@ def _run(cmd, what):
 
 
 def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
-                extra_flags: Optional[list] = None) -> str:
+                extra_flags: Optional[list] = None, tag: str = "") -> str:
     """Compile the library for packed model `m` (no-op when an up-to-date one exists).  The single
     source file is compiled as seven translation units in parallel (-DRBD_TU_*) and linked."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(BUILD_DIR, exist_ok=True)
     out = lib_path(m)
+    if tag:                                   # experiment builds live beside the real one
+        out = out[:-3] + f".{tag}.so"
     if not force and os.path.exists(out) and os.path.getmtime(out) >= _sources_mtime():
         return out
     hdr = header_path(m)
@@ -81,7 +84,7 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
     flags = list(HIPCC_FLAGS) + list(extra_flags or [])
 
     def compile_tu(tu):
-        obj = os.path.join(BUILD_DIR, f"obj_{m.hash}_{tu}.o")
+        obj = os.path.join(BUILD_DIR, f"obj_{m.hash}_{tag}_{tu}.o")
         cmd = [hipcc_path(), *[f for f in flags if f != "-shared"], f"-DRBD_TU_{tu}=1", "-include", hdr,
                "-c", src, "-o", obj]
         if verbose:

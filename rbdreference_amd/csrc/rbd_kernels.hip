@@ -142,11 +142,34 @@ RBD_DEV double from_odd_lane<double>(double x) {
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
+// Occupancy request (waves per SIMD) for the register allocator: fp32 state fits 168 VGPRs.
 template <class T>
-RBD_DEV void lds_add(T* p, T v) { atomicAdd(p, v); }
+constexpr int grad_min_waves() {
+#ifdef GRAD_MIN_WAVES
+  return GRAD_MIN_WAVES;
+#else
+  return sizeof(T) == 4 ? 3 : 1;
+#endif
+}
+// dc[i, c] is structurally non-zero only for related (ancestor/descendant) bodies.  Up to 72 such
+// pairs per lane are accumulated in registers; bigger robots accumulate in the LDS tile instead
+// (plain read-add-write: every address has exactly one owner lane; LDS float atomics measured ~4x
+// slower than that).
+constexpr int related_pairs() {
+  int k = 0;
+  for (int i = 0; i < N; ++i)
+    for (int c = 0; c < N; ++c) k += related(i, c) ? 1 : 0;
+  return k;
+}
+constexpr bool GRAD_ACC_IN_REGS = related_pairs() <= 72;
+// Opaque copy: the compiler cannot see that launder(x) == x, so values recomputed from laundered
+// inputs are NOT merged (CSE) with their first computation.  Used to trade ~400 cheap instructions
+// (the v/a recursion) for ~170 VGPRs that would otherwise stay live across the whole sweep.
+RBD_DEV float launder(float x) { asm volatile("" : "+v"(x)); return x; }
+RBD_DEV double launder(double x) { asm volatile("" : "+v"(x)); return x; }
 
 template <class T, bool HAS_QDD>
-__global__ __launch_bounds__(2 * grad_cfgs<T>()) void rnea_grad_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+__global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_grad_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ qdd, T grav, int use_damping,
                                                        long long B, T* __restrict__ c_out,
                                                        T* __restrict__ dcdu) {
@@ -171,17 +194,21 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>()) void rnea_grad_kernel(const T* 
     if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
   });
 
-  // ---- RNEA forward + backward: v, a, X v_p, X a_p per body and the ACCUMULATED forces -------
-  T v[N][6], a[N][6], xv[N][6], xa[N][6], f[N][6];
+  // ---- pass 1: RNEA forward + backward -> c and the ACCUMULATED forces f (:569-619) -----------
+  T f[N][6];
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-  sfor<0, N>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    constexpr int p = PARENT[j];
-    if constexpr (p < 0)
-      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv[j], xa[j], v[j], a[j], f[j]);
-    else
-      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv[j], xa[j], v[j], a[j], f[j]);
-  });
+  {
+    T v[N][6], a[N][6];
+    sfor<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      T xv[6], xa[6];
+      if constexpr (p < 0)
+        rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
+      else
+        rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
+    });
+  }
   T c[N];
   sfor_down<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
@@ -197,40 +224,45 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>()) void rnea_grad_kernel(const T* 
     sfor<0, N>([&](auto J) { c_out[b * N + decltype(J)::value] = c[decltype(J)::value]; });
   }
 
-  // ---- LDS accumulator tile: layout == HBM layout of dc_du for this block's configurations ----
-  T* acc = tile + slot * GRAD_TS + (isqd ? N : 0);   // acc[i * 2N + c]
-  // entries (i, c) with unrelated bodies are structurally zero and never touched below
-  sfor<0, N>([&](auto I) {
-    sfor<0, N>([&](auto C) {
-      constexpr int i = decltype(I)::value, cc = decltype(C)::value;
-      if constexpr (!related(i, cc)) acc[i * GRAD_ROW + cc] = T(0);
-    });
-  });
-
-  // ---- forward gradient sweep (:1139-1185, :1210-1252 fused; backward passes folded in) -------
+  // ---- pass 2: forward gradient sweep (:1139-1185, :1210-1252 fused; backward passes folded in)
+  // v, a are recomputed here from laundered inputs instead of being kept from pass 1.
   // Column slot s of body j = its ancestor-or-self at depth s.  dv/da[j][s] are this lane's
-  // derivative columns (dq columns on even lanes, dqd columns on odd lanes).
+  // derivative columns (dq columns on even lanes, dqd columns on odd lanes).  acc[i][c] collects
+  // dc[i, c] for related (i, c); everything is statically indexed => registers.
+  T acc[N][N];
+  T* my = tile + slot * GRAD_TS + (isqd ? N : 0);   // LDS image of this lane's half rows: my[i * 2N + c]
+  T v[N][6], a[N][6];
   T dv[N][MAXDEPTH][6], da[N][MAXDEPTH][6];
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int p = PARENT[j];
     constexpr int d = DEPTH[j];
-    const T qdj = qdv[j];
+    const JTrig<T> g{launder(tr[j].s), launder(tr[j].c)};
+    const T qdj = launder(qdv[j]);
+    const T qddj = HAS_QDD ? launder(qddv[j]) : T(0);
+    T xv[6], xa[6];
+    {
+      T fdead[6];
+      if constexpr (p < 0)
+        rnea_fwd_body<j, HAS_QDD>(g, qdj, qddj, grav, zero6, zero6, xv, xa, v[j], a[j], fdead);
+      else
+        rnea_fwd_body<j, HAS_QDD>(g, qdj, qddj, grav, v[p], a[p], xv, xa, v[j], a[j], fdead);
+    }
     // inherited columns: dv = X dv_p ; da = X da_p + qd_j crm(dv) S           (:1158,:1163,:1170)
     sfor<0, d>([&](auto Sx) {
       constexpr int s = decltype(Sx)::value;
-      xform<j>(tr[j], dv[p][s], dv[j][s]);
-      xform<j>(tr[j], da[p][s], da[j][s]);
+      xform<j>(g, dv[p][s], dv[j][s]);
+      xform<j>(g, da[p][s], da[j][s]);
       add_mxS<j>(dv[j][s], qdj, da[j][s]);
     });
     // own column: dq:  dv = crm(X v_p) S (0 at a root, :1157-1159);  da = qd crm(dv) S + crm(X a_p) S (:1170-1175)
     //             dqd: dv = S (:1231);                                da = qd crm(S) S (= 0) + crm(v_j) S (:1243)
     {
       T sdq[6], sS[6], e1[6], e2[6];
-      mxS<j>(xv[j], T(1), sdq);
+      mxS<j>(xv, T(1), sdq);
       sfor<0, 6>([&](auto R) { sS[decltype(R)::value] = T(0); });
       add_S<j>(T(1), sS);
-      mxS<j>(xa[j], T(1), e1);
+      mxS<j>(xa, T(1), e1);
       mxS<j>(v[j], T(1), e2);
       sfor<0, 6>([&](auto R) {
         constexpr int r = decltype(R)::value;
@@ -239,47 +271,62 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>()) void rnea_grad_kernel(const T* 
       });
       add_mxS<j>(dv[j][d], qdj, da[j][d]);
     }
-    // df = I da + crf(dv) (I v) + crf(v) (I dv)                               (:1179-1185)
-    T Iv[6];
-    cmatvec<MatI, j>(v[j], Iv);
-    T df[d + 1][6], phi[d + 1][6];
+    // Phi[i, j] = dv_dqd[:, i, j] lives on the odd lane of the pair
+    T phi[d + 1][6];
     sfor<0, d + 1>([&](auto Sx) {
       constexpr int s = decltype(Sx)::value;
-      T Idv[6];
-      cmatvec<MatI, j>(da[j][s], df[s]);
-      cmatvec<MatI, j>(dv[j][s], Idv);
-      fxv<true>(dv[j][s], Iv, df[s]);
-      fxv<true>(v[j], Idv, df[s]);
       sfor<0, 6>([&](auto R) { phi[s][decltype(R)::value] = from_odd_lane(dv[j][s][decltype(R)::value]); });
     });
+    T Iv[6];
+    cmatvec<MatI, j>(v[j], Iv);
     // extra dq term of the backward pass (:1292-1294): column j gains X_j^T fxS(S_j, f_j) at the
     // parent, i.e. rows i that are STRICT ancestors see  Phi[i, j]^T (-crm(f_j) S_j).
-    T dfx[6];
-    {
-      T w[6];
-      mxS<j>(f[j], T(-1), w);
-      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dfx[r] = df[d][r] + sel(isqd, T(0), w[r]); });
-    }
-    // dc[i, c] += Phi[i]^T df[c] for all ancestor-or-self pairs of j
-    sfor<0, d + 1>([&](auto Si) {
-      constexpr int si = decltype(Si)::value;
-      constexpr int row = anc_at(j, si);
-      sfor<0, d + 1>([&](auto Sc) {
-        constexpr int sc = decltype(Sc)::value;
-        constexpr int col = anc_at(j, sc);
-        T val;
-        if constexpr (sc == d && si < d) val = dot6(phi[si], dfx);
-        else val = dot6(phi[si], df[sc]);
-        if constexpr (si == d || sc == d) acc[row * GRAD_ROW + col] = val;   // first touch of (row, col)
-        else lds_add(&acc[row * GRAD_ROW + col], val);
+    T w[6];
+    mxS<j>(f[j], T(-1), w);
+    sfor<0, d + 1>([&](auto Sc) {
+      constexpr int sc = decltype(Sc)::value;
+      constexpr int col = anc_at(j, sc);
+      // df = I da + crf(dv) (I v) + crf(v) (I dv)                             (:1179-1185)
+      T df[6], Idv[6];
+      cmatvec<MatI, j>(da[j][sc], df);
+      cmatvec<MatI, j>(dv[j][sc], Idv);
+      fxv<true>(dv[j][sc], Iv, df);
+      fxv<true>(v[j], Idv, df);
+      // dc[i, c] += Phi[i]^T df[c] for all ancestor-or-self rows i of j
+      sfor<0, d + 1>([&](auto Si) {
+        constexpr int si = decltype(Si)::value;
+        constexpr int row = anc_at(j, si);
+        T val = dot6(phi[si], df);
+        if constexpr (sc == d && si < d) {
+          const T ex = dot6(phi[si], w);
+          val += sel(isqd, T(0), ex);
+        }
+        if constexpr (GRAD_ACC_IN_REGS) {
+          if constexpr (si == d || sc == d) acc[row][col] = val;   // first touch of (row, col)
+          else acc[row][col] += val;
+        } else {
+          if constexpr (si == d || sc == d) my[row * GRAD_ROW + col] = val;
+          else my[row * GRAD_ROW + col] += val;
+        }
       });
     });
   });
-  if (use_damping && isqd) {  // :1336-1341
-    sfor<0, N>([&](auto I) { constexpr int i = decltype(I)::value; lds_add(&acc[i * GRAD_ROW + i], T(DAMPING[i])); });
-  }
+
+  // ---- park the accumulators in the LDS image of the output tile, stream it out coalesced -----
+  sfor<0, N>([&](auto I) {
+    sfor<0, N>([&](auto C) {
+      constexpr int i = decltype(I)::value, cc = decltype(C)::value;
+      if constexpr (!related(i, cc)) {
+        my[i * GRAD_ROW + cc] = T(0);                                       // structural zero
+      } else if constexpr (GRAD_ACC_IN_REGS) {
+        if constexpr (i == cc) my[i * GRAD_ROW + cc] = acc[i][cc] + sel(use_damping != 0 && isqd, T(DAMPING[i]), T(0));  // :1336-1341
+        else my[i * GRAD_ROW + cc] = acc[i][cc];
+      } else if constexpr (i == cc) {
+        my[i * GRAD_ROW + cc] += sel(use_damping != 0 && isqd, T(DAMPING[i]), T(0));
+      }
+    });
+  });
   __syncthreads();
-  // ---- coalesced write-out of the tile ---------------------------------------------------------
   T* gdst = dcdu + cfg0 * GRAD_TILE;
   const int total = nvalid * GRAD_TILE;
 #pragma unroll 4
@@ -288,7 +335,6 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>()) void rnea_grad_kernel(const T* 
     gdst[g] = tile[g + cfg * (GRAD_TS - GRAD_TILE)];
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // minv: q -> Minv [B, n, n]                                                    (:630-806)
