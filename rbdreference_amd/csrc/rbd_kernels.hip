@@ -58,14 +58,17 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
   const int nvalid = rem < 64 ? (int)rem : 64;
   const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
 
+  // all input loads are issued before the first sincos (whose range-reduction branch would
+  // otherwise fence each load behind the previous joint's trig: 7 serialized HBM round trips)
   JTrig<T> tr[N];
-  T qdv[N], qddv[N];
+  T qv[N], qdv[N], qddv[N];
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    tr[j] = make_trig<j>(q[b * N + j]);
+    qv[j] = q[b * N + j];
     qdv[j] = qd[b * N + j];
     if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
   });
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
 
   T v[N][6], a[N][6], f[N][6];
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -184,15 +187,30 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   const long long rem = B - cfg0;
   const int nvalid = rem < CFGS ? (int)rem : CFGS;
   const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
+#ifdef RBD_EXP_STAMPS
+#define RBD_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+  unsigned long long stamps[8];
+#else
+#define RBD_STAMP(k) do {} while (0)
+#endif
+  RBD_STAMP(0);
 
+  // all input loads are issued before the first sincos (whose range-reduction branch would
+  // otherwise fence each load behind the previous joint's trig: 7 serialized HBM round trips)
   JTrig<T> tr[N];
-  T qdv[N], qddv[N];
+  T qv[N], qdv[N], qddv[N];
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    tr[j] = make_trig<j>(q[b * N + j]);
+    qv[j] = q[b * N + j];
     qdv[j] = qd[b * N + j];
     if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
   });
+#ifdef RBD_EXP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RBD_STAMP(1);
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
+  RBD_STAMP(2);
 
   // ---- pass 1: RNEA forward + backward -> c and the ACCUMULATED forces f (:569-619) -----------
   T f[N][6];
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     sfor<0, N>([&](auto J) { c_out[b * N + decltype(J)::value] = c[decltype(J)::value]; });
   }
 
+  RBD_STAMP(3);
   // ---- pass 2: forward gradient sweep (:1139-1185, :1210-1252 fused; backward passes folded in)
   // v, a are recomputed here from laundered inputs instead of being kept from pass 1.
   // Column slot s of body j = its ancestor-or-self at depth s.  dv/da[j][s] are this lane's
@@ -312,6 +331,7 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     });
   });
 
+  RBD_STAMP(4);
   // ---- park the accumulators in the LDS image of the output tile, stream it out coalesced -----
   sfor<0, N>([&](auto I) {
     sfor<0, N>([&](auto C) {
@@ -327,8 +347,27 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     });
   });
   __syncthreads();
+  RBD_STAMP(5);
+#ifdef RBD_EXP_STAMPS
+  if (lane == 0 && c_out != nullptr) {   // DIAGNOSTIC BUILD ONLY: phase durations overwrite c of the block's first row
+    for (int k = 0; k < 5; ++k) c_out[cfg0 * N + k] = (T)(float)(stamps[k + 1] - stamps[k]);
+    c_out[cfg0 * N + 5] = (T)(float)(stamps[0] & 0xffffff);
+  }
+#endif
   T* gdst = dcdu + cfg0 * GRAD_TILE;
   const int total = nvalid * GRAD_TILE;
+  constexpr int VE = 16 / sizeof(T);
+  if constexpr (GRAD_TS == GRAD_TILE && (CFGS * GRAD_TILE) % VE == 0) {
+    // LDS image == HBM image: 16-byte copies (block base is a multiple of CFGS * GRAD_TILE elements)
+    typedef T V __attribute__((ext_vector_type(VE)));
+    if (nvalid == CFGS) {
+      const V* src = reinterpret_cast<const V*>(tile);
+      V* dst = reinterpret_cast<V*>(gdst);
+#pragma unroll 4
+      for (int g = lane; g < CFGS * GRAD_TILE / VE; g += NT) dst[g] = src[g];
+      return;
+    }
+  }
 #pragma unroll 4
   for (int g = lane; g < total; g += NT) {
     int cfg = g / GRAD_TILE;
@@ -394,7 +433,9 @@ __global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, lo
   const bool valid = b0 < B;
   const long long b = valid ? b0 : B - 1;
   JTrig<T> tr[N];
-  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(q[b * N + j]); });
+  T qv[N];
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; qv[j] = q[b * N + j]; });
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
   T IA[N][6][6];
   sfor<0, N>([&](auto J) {
     sfor<0, 6>([&](auto R) {
