@@ -45,6 +45,48 @@ RBD_DEV void staged_store(T* lds, const T (&vals)[K], T* gdst, int lane, int nva
 // ---------------------------------------------------------------------------------------------
 // rnea:  (q, qd, qdd) -> c [B,n], v, a, f [B,6,n]   (f = ACCUMULATED force, :619, :628)
 // ---------------------------------------------------------------------------------------------
+// Opaque copy: the compiler cannot see that launder(x) == x, so values recomputed from laundered
+// inputs are NOT merged (CSE) with their first computation.  rnea_grad_kernel uses it to trade ~400
+// cheap instructions (the v/a recursion) for ~170 VGPRs that would otherwise stay live.
+RBD_DEV float launder(float x) { asm volatile("" : "+v"(x)); return x; }
+RBD_DEV double launder(double x) { asm volatile("" : "+v"(x)); return x; }
+
+// Ordering point: the six values pass through an empty volatile asm with a memory clobber, so code
+// that produces them stays above it and later memory reads stay below it.
+RBD_DEV void pin6(float (&x)[6]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]) : : "memory");
+}
+RBD_DEV void pin6(double (&x)[6]) {
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]) : : "memory");
+}
+
+// Robots with more than RNEA_REG_BODIES bodies cannot hold v, a, f of every body in registers
+// (18 n values); for them v and a are parked in LDS tiles as they are produced and flushed after the
+// forward pass, so only f (6 n) stays live across the backward pass.
+constexpr int RNEA_REG_BODIES = 10;
+constexpr bool RNEA_PARK_VA = N > RNEA_REG_BODIES;
+template <class T>
+constexpr bool rnea_two_tiles() { return 2ull * 64 * odd_pad<6 * N>() * sizeof(T) <= 150 * 1024; }
+template <class T>
+constexpr size_t rnea_lds_bytes(bool vaf) {
+  if (!vaf) return sizeof(T) * 64 * (size_t)odd_pad<N>();
+  const size_t one = sizeof(T) * 64 * (size_t)odd_pad<6 * N>();
+  return (RNEA_PARK_VA && rnea_two_tiles<T>()) ? 2 * one : one;
+}
+
+// stream a [64][KP]-strided LDS tile out as [nvalid][K] rows
+template <int K, class T>
+RBD_DEV void flush_tile(const T* lds, T* gdst, int lane, int nvalid) {
+  constexpr int KP = odd_pad<K>();
+  const int total = nvalid * K;
+#pragma unroll 4
+  for (int g = lane; g < total; g += 64) {
+    int cfg = g / K;
+    int r = g - cfg * K;
+    gdst[g] = lds[cfg * KP + r];
+  }
+}
+
 template <class T, bool HAS_QDD, bool WITH_VAF>
 __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                   const T* __restrict__ qdd, T grav, long long B,
@@ -57,9 +99,9 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
   const long long rem = B - cfg0;
   const int nvalid = rem < 64 ? (int)rem : 64;
   const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
+  constexpr int K6 = 6 * N;
+  constexpr int KP6 = odd_pad<K6>();
 
-  // all input loads are issued before the first sincos (whose range-reduction branch would
-  // otherwise fence each load behind the previous joint's trig: 7 serialized HBM round trips)
   JTrig<T> tr[N];
   T qv[N], qdv[N], qddv[N];
   sfor<0, N>([&](auto J) {
@@ -72,6 +114,10 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
 
   T v[N][6], a[N][6], f[N][6];
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  constexpr bool PARK = WITH_VAF && RNEA_PARK_VA;
+  constexpr bool TWO = rnea_two_tiles<T>();
+  T* ldsV = lds + lane * KP6;
+  T* ldsA = lds + (TWO ? 64 * KP6 : 0) + lane * KP6;
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int p = PARENT[j];
@@ -80,7 +126,39 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
       rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
     else
       rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
+    if constexpr (PARK) {   // reference layout (6, NB): element [r][j]
+      sfor<0, 6>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        ldsV[r * N + j] = v[j][r];
+        if constexpr (TWO) ldsA[r * N + j] = a[j][r];
+      });
+      pin6(f[j]);           // keep the bodies in program order (bounds the live v/a set)
+    }
   });
+  if constexpr (PARK) {
+    __syncthreads();
+    flush_tile<K6>(lds, v_out + cfg0 * K6, lane, nvalid);
+    if constexpr (TWO) {
+      flush_tile<K6>(lds + 64 * KP6, a_out + cfg0 * K6, lane, nvalid);
+    } else {
+      // a does not fit beside v: redo the cheap v/a recursion from laundered inputs and park a
+      __syncthreads();
+      T v2[N][6], a2[N][6];
+      sfor<0, N>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int p = PARENT[j];
+        const JTrig<T> g{launder(tr[j].s), launder(tr[j].c)};
+        T xv[6], xa[6], fdead[6];
+        if constexpr (p < 0)
+          rnea_fwd_body<j, HAS_QDD>(g, launder(qdv[j]), launder(qddv[j]), grav, zero6, zero6, xv, xa, v2[j], a2[j], fdead);
+        else
+          rnea_fwd_body<j, HAS_QDD>(g, launder(qdv[j]), launder(qddv[j]), grav, v2[p], a2[p], xv, xa, v2[j], a2[j], fdead);
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; ldsA[r * N + j] = a2[j][r]; });
+      });
+      __syncthreads();
+      flush_tile<K6>(lds, a_out + cfg0 * K6, lane, nvalid);
+    }
+  }
   // backward pass (:607-619)
   T c[N];
   sfor_down<0, N>([&](auto J) {
@@ -94,17 +172,19 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
     }
   });
 
-  staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
   if constexpr (WITH_VAF) {
     // reference layout (6, NB) per configuration: element [r][i]
-    T tmp[6 * N];
-    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = v[decltype(J)::value][decltype(R)::value]; }); });
-    staged_store<6 * N>(lds, tmp, v_out + cfg0 * 6 * N, lane, nvalid);
-    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = a[decltype(J)::value][decltype(R)::value]; }); });
-    staged_store<6 * N>(lds, tmp, a_out + cfg0 * 6 * N, lane, nvalid);
+    T tmp[K6];
+    if constexpr (!PARK) {
+      sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = v[decltype(J)::value][decltype(R)::value]; }); });
+      staged_store<K6>(lds, tmp, v_out + cfg0 * K6, lane, nvalid);
+      sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = a[decltype(J)::value][decltype(R)::value]; }); });
+      staged_store<K6>(lds, tmp, a_out + cfg0 * K6, lane, nvalid);
+    }
     sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
-    staged_store<6 * N>(lds, tmp, f_out + cfg0 * 6 * N, lane, nvalid);
+    staged_store<K6>(lds, tmp, f_out + cfg0 * K6, lane, nvalid);
   }
+  staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -145,13 +225,15 @@ RBD_DEV double from_odd_lane<double>(double x) {
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-// Occupancy request (waves per SIMD) for the register allocator: fp32 state fits 168 VGPRs.
+// Occupancy request (waves per SIMD) for the register allocator.  fp32 needs ~178 VGPRs at n = 7:
+// asking for 3 waves (168) makes the allocator spill ~17 values to scratch, which measured +45 % HBM
+// traffic (PMC) for no sustained speed-up; 2 waves run spill-free.
 template <class T>
 constexpr int grad_min_waves() {
 #ifdef GRAD_MIN_WAVES
   return GRAD_MIN_WAVES;
 #else
-  return sizeof(T) == 4 ? 3 : 1;
+  return sizeof(T) == 4 ? 2 : 1;
 #endif
 }
 // dc[i, c] is structurally non-zero only for related (ancestor/descendant) bodies.  Up to 72 such
@@ -165,11 +247,6 @@ constexpr int related_pairs() {
   return k;
 }
 constexpr bool GRAD_ACC_IN_REGS = related_pairs() <= 72;
-// Opaque copy: the compiler cannot see that launder(x) == x, so values recomputed from laundered
-// inputs are NOT merged (CSE) with their first computation.  Used to trade ~400 cheap instructions
-// (the v/a recursion) for ~170 VGPRs that would otherwise stay live across the whole sweep.
-RBD_DEV float launder(float x) { asm volatile("" : "+v"(x)); return x; }
-RBD_DEV double launder(double x) { asm volatile("" : "+v"(x)); return x; }
 
 template <class T, bool HAS_QDD>
 __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_grad_kernel(const T* __restrict__ q, const T* __restrict__ qd,
@@ -407,21 +484,17 @@ RBD_DEV void ws_store(T* ws, long long B, int i, long long b, const BodyCfg<T>& 
     dst[k] = x;
   });
 }
+// read one 12-scalar record from the LDS copy (three / six 16-byte reads)
 template <class T>
-RBD_DEV BodyCfg<T> ws_load(const T* ws, long long B, int i, long long b) {
+RBD_DEV void ws_read_lds(const T* recs, int i, T (&flat)[MINV_WS]) {
   constexpr int VE = 16 / sizeof(T);
   typedef T V __attribute__((ext_vector_type(VE)));
-  const V* src = reinterpret_cast<const V*>(ws + ((long long)i * B + b) * MINV_WS);
-  T flat[MINV_WS];
+  const V* src = reinterpret_cast<const V*>(recs + i * MINV_WS);
   sfor<0, MINV_WS / VE>([&](auto K) {
     constexpr int k = decltype(K)::value;
     const V x = src[k];
     sfor<0, VE>([&](auto E) { flat[k * VE + decltype(E)::value] = x[decltype(E)::value]; });
   });
-  BodyCfg<T> bc;
-  sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = flat[decltype(R)::value]; });
-  bc.Dinv = flat[6]; bc.s = flat[7]; bc.c = flat[8];
-  return bc;
 }
 
 constexpr int s_index(int i) { return (JTYPE[i] == 0 ? 0 : 3) + AXIS[i]; }
@@ -475,6 +548,9 @@ __global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, lo
   });
 }
 
+#ifndef MINV_COLS_MIN_WAVES
+#define MINV_COLS_MIN_WAVES 4
+#endif
 constexpr int MINV_LC = (N <= 8) ? 8 : (N <= 16) ? 16 : (N <= 32) ? 32 : 64;   // lanes per configuration
 constexpr int MINV_CPB = 64 / MINV_LC;                                         // configurations per wave
 constexpr int MINV_TS = (N * N) | 1;                                           // LDS tile stride (odd)
@@ -485,26 +561,54 @@ constexpr unsigned long long subtree_mask(int i) {
 }
 
 template <class T>
-__global__ __launch_bounds__(64) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
+__global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
                                                        T* __restrict__ Minv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);
+  T* wsl = reinterpret_cast<T*>(smem_raw);                 // [MINV_CPB][N][MINV_WS] per-body records
+  T* tile = wsl + MINV_CPB * N * MINV_WS;                  // [MINV_CPB][MINV_TS] output image
   const int lane = threadIdx.x;
   const int j = lane % MINV_LC;          // this lane's column
   const int slot = lane / MINV_LC;
   const long long cfg0 = (long long)blockIdx.x * MINV_CPB;
   const long long rem = B - cfg0;
   const int nvalid = rem < MINV_CPB ? (int)rem : MINV_CPB;
-  const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
+
+  // stage the block's {U, 1/D, sin, cos} records in LDS once (both sweeps read them; every lane of a
+  // configuration reads the same record => LDS broadcast instead of 2 x N dependent L2 round trips)
+  {
+    constexpr int VE = 16 / sizeof(T);
+    constexpr int VPB = MINV_WS / VE;                      // 16-byte pieces per record
+    typedef T V __attribute__((ext_vector_type(VE)));
+    V* dst = reinterpret_cast<V*>(wsl);
+#pragma unroll 2
+    for (int idx = lane; idx < MINV_CPB * N * VPB; idx += 64) {
+      const int piece = idx % VPB;
+      const int rec = idx / VPB;
+      const int body = rec % N;
+      const int cs = rec / N;
+      const long long bb = cfg0 + (cs < nvalid ? cs : nvalid - 1);
+      dst[idx] = reinterpret_cast<const V*>(ws + ((long long)body * B + bb) * MINV_WS)[piece];
+    }
+  }
+  __syncthreads();
+  const T* myws = wsl + slot * N * MINV_WS;
 
   T mcol[N];
   T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  // Records are read one body ahead of their use; pin6() at the end of each body is an ordering
+  // point that keeps the compiler from hoisting ALL N record reads to the top of the kernel (which
+  // costs 9 N VGPRs and spills: the instruction selector otherwise schedules every LDS read first).
+  T rec[N][MINV_WS];
+  ws_read_lds(myws, N - 1, rec[N - 1]);
   // ---- backward sweep (:665-726), column j -----------------------------------------------------
   sfor_down<0, N>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int p = PARENT[i];
     constexpr unsigned long long mask = subtree_mask(i);
-    const BodyCfg<T> bc = ws_load(ws, B, i, b);
+    if constexpr (i > 0) ws_read_lds(myws, i - 1, rec[i - 1]);
+    BodyCfg<T> bc;
+    sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = rec[i][decltype(R)::value]; });
+    bc.Dinv = rec[i][6]; bc.s = rec[i][7]; bc.c = rec[i][8];
     const bool insub = ((mask >> j) & 1ull) != 0;
     T m = sel(j == i, bc.Dinv, -(bc.Dinv * S_dot<i>(Fj)));         // :700, :702-708
     m = sel(insub, m, T(0));
@@ -516,24 +620,34 @@ __global__ __launch_bounds__(64) void minv_cols_kernel(const T* __restrict__ ws,
       xform_T<i>(g, t, y);                                                                                  // :724-726
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fj[r] = sel(insub, y[r], Fj[r]); });
     }
+    pin6(Fj);
   });
   // ---- forward sweep (:760-781), column j ------------------------------------------------------
   T Ff[N][6];
+  // (the memory clobbers of pin6() also stop the compiler from forwarding the backward sweep's
+  // record reads to the forward sweep, which would keep all 9 N values live in between)
+  const T* myws2 = myws;
+  T rec2[N][MINV_WS];
+  ws_read_lds(myws2, 0, rec2[0]);
   sfor<0, N>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int p = PARENT[i];
     constexpr int si = s_index(i);
+    if constexpr (i + 1 < N) ws_read_lds(myws2, i + 1, rec2[i + 1]);
     if constexpr (p < 0) {
       sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
       Ff[i][si] = mcol[i];                                                                        // :781
     } else {
-      const BodyCfg<T> bc = ws_load(ws, B, i, b);
+      BodyCfg<T> bc;
+      sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = rec2[i][decltype(R)::value]; });
+      bc.Dinv = rec2[i][6]; bc.s = rec2[i][7]; bc.c = rec2[i][8];
       const JTrig<T> g{bc.s, bc.c};
       xform<i>(g, Ff[p], Ff[i]);
       const T m = fma_(-bc.Dinv, dot6(bc.U, Ff[i]), mcol[i]);                                     // :771-773
       mcol[i] = m;
       Ff[i][si] += m;                                                                             // :774-776
     }
+    pin6(Ff[i]);
   });
   // ---- symmetrise (:799-804) through LDS, then stream the tile out ------------------------------
   T* myt = tile + slot * MINV_TS;
@@ -620,8 +734,8 @@ int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* 
   const int64_t blocks = (B + 63) / 64;
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea: B too large");
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = sizeof(T) * 64 * (size_t)odd_pad<6 * N>();
-  const size_t lds_c = sizeof(T) * 64 * (size_t)odd_pad<N>();
+  const size_t lds = rnea_lds_bytes<T>(true);
+  const size_t lds_c = rnea_lds_bytes<T>(false);
   int rc;
 #define RBD_LAUNCH_RNEA(HQ, VAF, LDS)                                                              \
   do {                                                                                             \
@@ -682,7 +796,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase A launch");
-  const size_t lds = sizeof(T) * (size_t)MINV_CPB * MINV_TS;
+  const size_t lds = sizeof(T) * ((size_t)MINV_CPB * MINV_TS + (size_t)MINV_CPB * N * MINV_WS);
   auto k = minv_cols_kernel<T>;
   int rc;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;

@@ -39,6 +39,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     res = {t: [] for t, _ in fns}
     ref = None
+    ITERS = int(os.environ.get("EXP_ITERS", "10"))
     for rnd in range(6):
         for tag, f in fns:
             for _ in range(3):
@@ -46,10 +47,10 @@ def main():
             torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10):
+            for _ in range(ITERS):
                 f(q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), -9.81, 0, B, c.data_ptr(), dc.data_ptr(), st)
             e1.record(); torch.cuda.synchronize()
-            res[tag].append(e0.elapsed_time(e1) / 10)
+            res[tag].append(e0.elapsed_time(e1) / ITERS)
             if rnd == 0:
                 if tag == "base":
                     ref = dc.clone()
