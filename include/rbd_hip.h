@@ -78,6 +78,26 @@ int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void*
 int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* RBDReference.forward_dynamics(q, qd, u)                 (RBDReference.py:1371-1374)
+ *   qdd = minv(q) @ (u - rnea(q, qd)[0])        u, qdd : [B, n]
+ * RBDReference.forward_dynamics_grad(q, qd, u)            (RBDReference.py:1376-1384)
+ *   dqdd_du : [B, n, 2n] = [qdd_dq | qdd_dqd] = -minv(q) @ rnea_grad(q, qd, qdd)  (the reference
+ *   returns the two halves as a tuple); qdd (nullable) also receives the forward dynamics itself.
+ *   Three / four launches on `stream`: rnea (bias force), minv phases A and B with the
+ *   Minv (u - c) product fused into phase B, rnea_grad with the -Minv product fused into its epilogue.
+ *   workspace: device scratch of at least rbd_fd_workspace_bytes(B, sizeof(T)) bytes, 16-byte aligned. */
+size_t rbd_fd_workspace_bytes(int64_t B, int elem_size);
+int rbd_forward_dynamics_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
+                             float* qdd, void* workspace, size_t workspace_bytes, void* stream);
+int rbd_forward_dynamics_f64(const double* q, const double* qd, const double* u, double gravity, int64_t B,
+                             double* qdd, void* workspace, size_t workspace_bytes, void* stream);
+int rbd_forward_dynamics_grad_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
+                                  float* qdd, float* dqdd_du, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int rbd_forward_dynamics_grad_f64(const double* q, const double* qd, const double* u, double gravity,
+                                  int64_t B, double* qdd, double* dqdd_du, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,8 @@ EXPORTED_SYMBOLS = [
     "rbd_abi_version", "rbd_last_error", "rbd_model_info",
     "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
     "rbd_minv_workspace_bytes", "rbd_minv_f32", "rbd_minv_f64",
+    "rbd_fd_workspace_bytes", "rbd_forward_dynamics_f32", "rbd_forward_dynamics_f64",
+    "rbd_forward_dynamics_grad_f32", "rbd_forward_dynamics_grad_f64",
 ]
 
 
@@ -55,8 +57,17 @@ def _declare(lib):
         f = getattr(lib, f"rbd_minv_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        f = getattr(lib, f"rbd_forward_dynamics_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]
+        f = getattr(lib, f"rbd_forward_dynamics_grad_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                      c_void_p]
     lib.rbd_minv_workspace_bytes.restype = c_size_t
     lib.rbd_minv_workspace_bytes.argtypes = [c_int64, c_int]
+    lib.rbd_fd_workspace_bytes.restype = c_size_t
+    lib.rbd_fd_workspace_bytes.argtypes = [c_int64, c_int]
 
 
 class RbdLibrary:

@@ -141,3 +141,37 @@ class RBDReference:
             self._lib.check(self._fn("rbd_minv", dt)(
                 self._ptr(q), B, 1 if output_dense else 0, self._ptr(M), ws.data_ptr(), wsb, st))
         return self._ret(M, unb, is_np)
+
+    # ---- next row of SURVEY.md §8f: forward dynamics on top of the three kernels --------------
+    def _fd(self, q, qd, u, GRAVITY, want_grad):
+        (q, qd, u), unb, is_np, dev, dt = self._prep(q, qd, u)
+        B = q.shape[0]
+        esz = 4 if dt == torch.float32 else 8
+        with torch.cuda.device(dev):
+            qdd = torch.empty((B, self.n), device=dev, dtype=dt)
+            wsb = int(self._lib.lib.rbd_fd_workspace_bytes(B, esz))
+            ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if want_grad:
+                d = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
+                self._lib.check(self._fn("rbd_forward_dynamics_grad", dt)(
+                    self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
+                    self._ptr(d), ws.data_ptr(), wsb, st))
+                return qdd, d, unb, is_np
+            self._lib.check(self._fn("rbd_forward_dynamics", dt)(
+                self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
+                ws.data_ptr(), wsb, st))
+            return qdd, None, unb, is_np
+
+    def forward_dynamics(self, q, qd, u, GRAVITY=-9.81):
+        """RBDReference.forward_dynamics (``RBDReference.py:1371-1374``): ``minv(q) @ (u - c(q, qd))``."""
+        qdd, _, unb, is_np = self._fd(q, qd, u, GRAVITY, False)
+        return self._ret(qdd, unb, is_np)
+
+    def forward_dynamics_grad(self, q, qd, u, GRAVITY=-9.81):
+        """RBDReference.forward_dynamics_grad (``RBDReference.py:1376-1384``) -> ``(qdd_dq, qdd_dqd)``,
+        each ``(n, n)`` per configuration (views of one ``[B, n, 2n]`` buffer for tensor inputs)."""
+        _, d, unb, is_np = self._fd(q, qd, u, GRAVITY, True)
+        n = self.n
+        d = self._ret(d, unb, is_np)
+        return d[..., :n], d[..., n:]

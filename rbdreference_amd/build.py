@@ -54,7 +54,8 @@ def _sources_mtime() -> float:
     return t
 
 
-TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64"]
+TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64",
+                     "FD_F32", "FD_F64"]
 _HIPCC_SLOTS = threading.BoundedSemaphore(max(1, (os.cpu_count() or 2)))
 
 

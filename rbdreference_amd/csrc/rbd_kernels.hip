@@ -248,11 +248,16 @@ constexpr int related_pairs() {
 }
 constexpr bool GRAD_ACC_IN_REGS = related_pairs() <= 72;
 
-template <class T, bool HAS_QDD>
+// FDG = forward_dynamics_grad epilogue (:1376-1384): the accumulated dc_du block of each lane is
+// multiplied by -Minv (read from `minv_in`, [B, n, n], prefetched into LDS at kernel start) before
+// it is parked, so  [qdd_dq | qdd_dqd] = -Minv [dc_dq | dc_dqd]  costs no extra HBM round trip.
+// Only available when the accumulators live in registers (GRAD_ACC_IN_REGS).
+template <class T, bool HAS_QDD, bool FDG>
 __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_grad_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ qdd, T grav, int use_damping,
                                                        long long B, T* __restrict__ c_out,
-                                                       T* __restrict__ dcdu) {
+                                                       T* __restrict__ dcdu, const T* __restrict__ minv_in) {
+  static_assert(!FDG || GRAD_ACC_IN_REGS, "fused -Minv epilogue needs register accumulators");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
@@ -271,6 +276,11 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
 #define RBD_STAMP(k) do {} while (0)
 #endif
   RBD_STAMP(0);
+  T* mtile = tile + CFGS * GRAD_TS;      // FDG: [CFGS][N*N] copy of Minv
+  if constexpr (FDG) {
+    const T* msrc = minv_in + cfg0 * (N * N);
+    for (int g = lane; g < nvalid * N * N; g += NT) mtile[g] = msrc[g];
+  }
 
   // all input loads are issued before the first sincos (whose range-reduction branch would
   // otherwise fence each load behind the previous joint's trig: 7 serialized HBM round trips)
@@ -409,6 +419,29 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   });
 
   RBD_STAMP(4);
+  if constexpr (FDG) {
+    // out[i][c] = - sum_k Minv[i][k] dc[k][c]; dc[k][c] is structurally zero for unrelated (k, c)
+    __syncthreads();                       // mtile is complete (written by other lanes at the start)
+    const T* mt = mtile + (slot < nvalid ? slot : 0) * (N * N);
+    sfor<0, N>([&](auto C) {
+      constexpr int cc = decltype(C)::value;
+      T colv[N];
+      sfor<0, N>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if constexpr (related(k, cc)) colv[k] = acc[k][cc] + ((k == cc) ? sel(use_damping != 0 && isqd, T(DAMPING[k]), T(0)) : T(0));
+        else colv[k] = T(0);
+      });
+      sfor<0, N>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        T o = T(0);
+        sfor<0, N>([&](auto K) {
+          constexpr int k = decltype(K)::value;
+          if constexpr (related(k, cc)) o = fma_(-mt[i * N + k], colv[k], o);
+        });
+        my[i * GRAD_ROW + cc] = o;
+      });
+    });
+  } else
   // ---- park the accumulators in the LDS image of the output tile, stream it out coalesced -----
   sfor<0, N>([&](auto I) {
     sfor<0, N>([&](auto C) {
@@ -562,7 +595,8 @@ constexpr unsigned long long subtree_mask(int i) {
 
 template <class T>
 __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
-                                                       T* __restrict__ Minv) {
+                                                       T* __restrict__ Minv, const T* __restrict__ u_in,
+                                                       const T* __restrict__ c_in, T* __restrict__ qdd_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* wsl = reinterpret_cast<T*>(smem_raw);                 // [MINV_CPB][N][MINV_WS] per-body records
   T* tile = wsl + MINV_CPB * N * MINV_WS;                  // [MINV_CPB][MINV_TS] output image
@@ -659,12 +693,45 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
     });
   }
   __syncthreads();
-  T* gdst = Minv + cfg0 * (N * N);
-  const int total = nvalid * N * N;
+  if (qdd_out != nullptr) {
+    // forward_dynamics epilogue (:1371-1374): qdd = Minv (u - c); lane j owns row j of the dense tile.
+    // (u - c) is parked in the record area, which both sweeps have finished reading.
+    T* tau = wsl + slot * N;
+    if (j < N && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
+    __syncthreads();
+    if (j < N && slot < nvalid) {
+      T o = T(0);
+      sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[j * N + k], tau[k], o); });
+      qdd_out[(cfg0 + slot) * N + j] = o;
+    }
+  }
+  if (Minv != nullptr) {
+    T* gdst = Minv + cfg0 * (N * N);
+    const int total = nvalid * N * N;
 #pragma unroll 4
-  for (int g = lane; g < total; g += 64) {
-    int cfg = g / (N * N);
-    gdst[g] = tile[g + cfg * (MINV_TS - N * N)];
+    for (int g = lane; g < total; g += 64) {
+      int cfg = g / (N * N);
+      gdst[g] = tile[g + cfg * (MINV_TS - N * N)];
+    }
+  }
+}
+
+// out[b] = -Minv[b] dc_du[b]  ([n, n] x [n, 2n]) for robots whose rnea_grad accumulates in LDS
+// (no fused epilogue): one thread per (configuration, output column), plain loops.
+template <class T>
+__global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict__ Minv, const T* __restrict__ dcdu,
+                                                            long long B, T* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * 2 * N) return;
+  const long long b = t / (2 * N);
+  const int c = (int)(t - b * 2 * N);
+  const T* M = Minv + b * N * N;
+  const T* D = dcdu + b * 2 * N * N;
+  T* O = out + b * 2 * N * N;
+  for (int i = 0; i < N; ++i) {
+    T o = T(0);
+    for (int k = 0; k < N; ++k) o = fma_(-M[i * N + k], D[k * 2 * N + c], o);
+    O[i * 2 * N + c] = o;
   }
 }
 
@@ -679,10 +746,10 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
 
 // The library is built from several translation units of this one file (rbdreference_amd/build.py
 // compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
-// _MINV_F32, _MINV_F64; no RBD_TU_* macro at all = everything in one unit.
+// _MINV_F32, _MINV_F64, _FD_F32, _FD_F64; no RBD_TU_* macro at all = everything in one unit.
 #if !defined(RBD_TU_COMMON) && !defined(RBD_TU_RNEA_F32) && !defined(RBD_TU_RNEA_F64) && \
     !defined(RBD_TU_GRAD_F32) && !defined(RBD_TU_GRAD_F64) && !defined(RBD_TU_MINV_F32) && \
-    !defined(RBD_TU_MINV_F64)
+    !defined(RBD_TU_MINV_F64) && !defined(RBD_TU_FD_F32) && !defined(RBD_TU_FD_F64)
 #define RBD_TU_COMMON 1
 #define RBD_TU_RNEA_F32 1
 #define RBD_TU_RNEA_F64 1
@@ -690,6 +757,8 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
 #define RBD_TU_GRAD_F64 1
 #define RBD_TU_MINV_F32 1
 #define RBD_TU_MINV_F64 1
+#define RBD_TU_FD_F32 1
+#define RBD_TU_FD_F64 1
 #endif
 
 // thread-local message buffer behind rbd_last_error(); one instance, owned by the COMMON unit
@@ -752,40 +821,44 @@ int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* 
   return 0;
 }
 
-template <class T>
-int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
-                     T* c, T* dc_du, void* stream) {
+// launches exactly one instantiation (the FD translation units use this to avoid compiling the
+// variants they never call)
+template <class T, bool HAS_QDD, bool FDG>
+int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                      T* c, T* dc_du, void* stream, const T* minv_in) {
   using namespace rbdk;
-  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
-  if (B == 0) return 0;
-  if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
   constexpr int CFGS = grad_cfgs<T>();
   const int64_t blocks = (B + CFGS - 1) / CFGS;
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
-  const size_t lds = sizeof(T) * (size_t)CFGS * GRAD_TS;
+  const size_t lds = sizeof(T) * ((size_t)CFGS * GRAD_TS + (FDG ? (size_t)CFGS * N * N : 0));
   if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
-  hipStream_t s = (hipStream_t)stream;
+  auto k = rnea_grad_kernel<T, HAS_QDD, FDG>;
   int rc;
-  if (qdd) {
-    auto k = rnea_grad_kernel<T, true>;
-    if ((rc = ensure_lds(k, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(2 * CFGS), lds, s, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
-  } else {
-    auto k = rnea_grad_kernel<T, false>;
-    if ((rc = ensure_lds(k, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(2 * CFGS), lds, s, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
-  }
+  if ((rc = ensure_lds(k, lds)) != 0) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(2 * CFGS), lds, (hipStream_t)stream, q, qd, qdd, gravity,
+                     use_damping, (long long)B, c, dc_du, minv_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
   return 0;
 }
 
 template <class T>
-int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspace, size_t wsb, void* stream) {
+int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                     T* c, T* dc_du, void* stream) {
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
+  if (qdd) return rnea_grad_launch1<T, true, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
+  return rnea_grad_launch1<T, false, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
+}
+
+template <class T>
+int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspace, size_t wsb, void* stream,
+                const T* u = nullptr, const T* cbias = nullptr, T* qdd = nullptr) {
   using namespace rbdk;
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
-  if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  if (!q || (!Minv && !qdd)) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
   const size_t need = (size_t)B * N * MINV_WS * sizeof(T);
   if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
@@ -800,10 +873,74 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   auto k = minv_cols_kernel<T>;
   int rc;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)blocksB), dim3(64), lds, s, (const T*)ws, (long long)B, output_dense, Minv);
+  hipLaunchKernelGGL(k, dim3((unsigned)blocksB), dim3(64), lds, s, (const T*)ws, (long long)B, output_dense, Minv, u, cbias, qdd);
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase B launch");
   return 0;
+}
+
+// ---- forward dynamics: compositions of the three kernels with fused epilogues ----
+constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+template <class T>
+struct FdWorkspace {
+  size_t off_minv_ws, off_c, off_minv, off_qdd, off_dcdu, total;
+  explicit FdWorkspace(int64_t B) {
+    using namespace rbdk;
+    size_t o = 0;
+    off_minv_ws = o; o += align16((size_t)B * N * MINV_WS * sizeof(T));
+    off_c = o;       o += align16((size_t)B * N * sizeof(T));
+    off_minv = o;    o += align16((size_t)B * N * N * sizeof(T));
+    off_qdd = o;     o += align16((size_t)B * N * sizeof(T));
+    off_dcdu = o;    o += GRAD_ACC_IN_REGS ? 0 : align16((size_t)B * 2 * N * N * sizeof(T));
+    total = o;
+  }
+};
+
+template <class T>
+int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, T* dqdd_du, bool want_grad,
+              void* workspace, size_t wsb, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !u) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: q, qd, u must be non-null");
+  if (want_grad ? !dqdd_du : !qdd) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: output pointer is null");
+  const FdWorkspace<T> L(B);
+  if (!workspace || wsb < L.total) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics: workspace missing or smaller than rbd_fd_workspace_bytes()");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics: workspace must be 16-byte aligned");
+  char* w = reinterpret_cast<char*>(workspace);
+  T* c = reinterpret_cast<T*>(w + L.off_c);
+  T* Mi = reinterpret_cast<T*>(w + L.off_minv);
+  T* qdd_buf = qdd ? qdd : reinterpret_cast<T*>(w + L.off_qdd);
+  int rc;
+  // c = rnea(q, qd) with qdd = None (:1372)
+  {
+    const int64_t blocks = (B + 63) / 64;
+    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B too large");
+    auto k = rnea_kernel<T, false, false>;
+    const size_t lds = rnea_lds_bytes<T>(false);
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)nullptr, gravity,
+                       (long long)B, c, (T*)nullptr, (T*)nullptr, (T*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics rnea launch");
+  }
+  // qdd = Minv (u - c) (:1373-1374); Minv itself is kept only when the gradient needs it
+  if ((rc = minv_launch<T>(q, B, 1, want_grad ? Mi : nullptr, w + L.off_minv_ws, (size_t)B * N * MINV_WS * sizeof(T),
+                           stream, u, c, qdd_buf)) != 0) return rc;
+  if (!want_grad) return 0;
+  // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
+  if constexpr (GRAD_ACC_IN_REGS) {
+    return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);
+  } else {
+    T* dc = reinterpret_cast<T*>(w + L.off_dcdu);
+    if ((rc = rnea_grad_launch1<T, true, false>(q, qd, qdd_buf, gravity, 0, B, nullptr, dc, stream, nullptr)) != 0) return rc;
+    const int64_t threads = B * 2 * N;
+    hipLaunchKernelGGL(fd_grad_apply_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad apply launch");
+    return 0;
+  }
 }
 }  // namespace
 
@@ -831,6 +968,12 @@ int rbd_model_info(rbd_model_info_t* out) {
 size_t rbd_minv_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
   return (size_t)B * rbdm::N * rbdk::MINV_WS * (size_t)elem_size;
+}
+size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {
+  if (B <= 0) return 0;
+  if (elem_size == 4) return FdWorkspace<float>(B).total;
+  if (elem_size == 8) return FdWorkspace<double>(B).total;
+  return 0;
 }
 #endif
 #ifdef RBD_TU_RNEA_F32
@@ -861,6 +1004,26 @@ int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, doub
 int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void* workspace,
                  size_t workspace_bytes, void* stream) {
   return minv_launch<float>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+}
+#endif
+#ifdef RBD_TU_FD_F32
+int rbd_forward_dynamics_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
+                             float* qdd, void* workspace, size_t workspace_bytes, void* stream) {
+  return fd_launch<float>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
+}
+int rbd_forward_dynamics_grad_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
+                                  float* qdd, float* dqdd_du, void* workspace, size_t workspace_bytes, void* stream) {
+  return fd_launch<float>(q, qd, u, gravity, B, qdd, dqdd_du, true, workspace, workspace_bytes, stream);
+}
+#endif
+#ifdef RBD_TU_FD_F64
+int rbd_forward_dynamics_f64(const double* q, const double* qd, const double* u, double gravity, int64_t B,
+                             double* qdd, void* workspace, size_t workspace_bytes, void* stream) {
+  return fd_launch<double>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
+}
+int rbd_forward_dynamics_grad_f64(const double* q, const double* qd, const double* u, double gravity, int64_t B,
+                                  double* qdd, double* dqdd_du, void* workspace, size_t workspace_bytes, void* stream) {
+  return fd_launch<double>(q, qd, u, gravity, B, qdd, dqdd_du, true, workspace, workspace_bytes, stream);
 }
 #endif
 #ifdef RBD_TU_MINV_F64

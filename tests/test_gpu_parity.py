@@ -218,3 +218,40 @@ def test_full_size_properties(name, B):
     check("dc_du sample", dc[tidx], dc_ref, TOL32)
     check("c sample", c[tidx], c_ref, TOL32)
     check("minv sample", Mi[tidx], orc.minv(om, qs), TOL32 * (10 if n >= 30 else 1))
+
+
+# ---- next row: forward dynamics compositions ------------------------------------
+@pytest.mark.parametrize("name", all_golden_names())
+def test_forward_dynamics_vs_golden(name, prec):
+    """forward_dynamics / forward_dynamics_grad (RBDReference.py:1371-1384) against the reference's
+    own outputs.  fp32 tolerance is looser than for rnea_grad: the result is multiplied by Minv,
+    whose condition number (1e2..1e4 for these robots) amplifies input rounding."""
+    dt, tol = prec
+    torch = _torch()
+    g = load_golden(name); rbd = rbd_for(name)
+    q, qd, u = dev_tensors(dt, g["q"], g["qd"], g["qdd"])       # gen_golden used u = qdd
+    tol_fd = 5e-4 if dt == torch.float32 else 1e-9
+    check("fd_qdd", rbd.forward_dynamics(q, qd, u), g["fd_qdd"], tol_fd)
+    a, b = rbd.forward_dynamics_grad(q, qd, u)
+    check("fd_dq", a.contiguous(), g["fd_dq"], tol_fd)
+    check("fd_dqd", b.contiguous(), g["fd_dqd"], tol_fd)
+
+
+def test_forward_dynamics_round_trip_full_size():
+    """rnea(q, qd, forward_dynamics(q, qd, u)) == u at B = 1M (fp32), ragged B, numpy path."""
+    torch = _torch()
+    rbd = rbd_for("iiwa_like")
+    for B in (1 << 20, 1000):
+        gen = torch.Generator(device="cuda:0"); gen.manual_seed(B)
+        q = (torch.rand((B, 7), device="cuda:0", generator=gen) * 2 - 1) * np.pi
+        qd = torch.rand((B, 7), device="cuda:0", generator=gen) * 2 - 1
+        u = (torch.rand((B, 7), device="cuda:0", generator=gen) * 2 - 1) * 10
+        qdd = rbd.forward_dynamics(q, qd, u)
+        c, _, _, _ = rbd.rnea(q, qd, qdd, outputs="c")
+        err = ((c - u).abs().amax(dim=1) / u.abs().amax(dim=1)).max().item()
+        assert err < 2e-3, err
+    g = load_golden("iiwa_like")
+    out = rbd.forward_dynamics(g["q"][1], g["qd"][1], g["qdd"][1])
+    assert isinstance(out, np.ndarray) and rel_err_rows(out[None], g["fd_qdd"][1:2]) < 1e-9
+    a, b = rbd.forward_dynamics_grad(g["q"][1], g["qd"][1], g["qdd"][1])
+    assert a.shape == (7, 7) and rel_err_rows(np.ascontiguousarray(b)[None], g["fd_dqd"][1:2]) < 1e-9
