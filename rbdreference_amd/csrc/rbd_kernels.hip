@@ -192,10 +192,53 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
 // ---------------------------------------------------------------------------------------------
 constexpr int GRAD_ROW = 2 * N;               // one output row: [dc_dq[i,:] | dc_dqd[i,:]]
 constexpr int GRAD_TILE = 2 * N * N;          // floats per configuration
+// Independent roots (e.g. the four legs of the quadruped) are processed one after the other; when
+// every root's subtree occupies a contiguous index range (DFS numbering) each root is a "group"
+// whose output rows are staged and flushed on their own, so the LDS tile only has to hold the
+// largest group.  Otherwise the whole robot is one group.
+constexpr int root_of(int j) {
+  while (PARENT[j] != -1) j = PARENT[j];
+  return j;
+}
+constexpr int last_of_root(int r) {
+  int m = r;
+  for (int j = 0; j < N; ++j)
+    if (root_of(j) == r) m = j;
+  return m;
+}
+constexpr bool roots_contiguous() {
+  for (int j = 0; j < N; ++j) {
+    const int r = root_of(j);
+    for (int k = r; k <= last_of_root(r); ++k)
+      if (root_of(k) != r) return false;
+  }
+  return true;
+}
+constexpr bool GRAD_PER_ROOT = roots_contiguous();
+constexpr bool grp_head(int rt) { return GRAD_PER_ROOT ? PARENT[rt] == -1 : rt == 0; }
+constexpr bool grp_has(int rt, int j) { return GRAD_PER_ROOT ? root_of(j) == rt : true; }
+constexpr int grp_row0(int rt) { return GRAD_PER_ROOT ? rt : 0; }
+constexpr int grp_rows(int rt) { return GRAD_PER_ROOT ? last_of_root(rt) - rt + 1 : N; }
+constexpr int grp_first() {
+  for (int r = 0; r < N; ++r)
+    if (grp_head(r)) return r;
+  return 0;
+}
+constexpr int grp_next(int rt) {   // next group head after rt, -1 if none
+  for (int r = rt + 1; r < N; ++r)
+    if (grp_head(r)) return r;
+  return -1;
+}
+constexpr int grad_max_rows() {
+  int m = 0;
+  for (int r = 0; r < N; ++r)
+    if (grp_head(r) && grp_rows(r) > m) m = grp_rows(r);
+  return m;
+}
 // LDS stride between configurations: == 2 (mod 32) keeps the 16 configurations of a 32-lane
 // LDS group on distinct even banks; the odd lane's +N offset lands on the odd banks when N is odd.
 constexpr int grad_tile_stride() {
-  int s = GRAD_TILE;
+  int s = grad_max_rows() * GRAD_ROW;
   while (s % 32 != 2) ++s;
   return s;
 }
@@ -248,6 +291,7 @@ constexpr int related_pairs() {
 }
 constexpr bool GRAD_ACC_IN_REGS = related_pairs() <= 72;
 
+
 // FDG = forward_dynamics_grad epilogue (:1376-1384): the accumulated dc_du block of each lane is
 // multiplied by -Minv (read from `minv_in`, [B, n, n], prefetched into LDS at kernel start) before
 // it is parked, so  [qdd_dq | qdd_dqd] = -Minv [dc_dq | dc_dqd]  costs no extra HBM round trip.
@@ -282,51 +326,75 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     for (int g = lane; g < nvalid * N * N; g += NT) mtile[g] = msrc[g];
   }
 
-  // all input loads are issued before the first sincos (whose range-reduction branch would
-  // otherwise fence each load behind the previous joint's trig: 7 serialized HBM round trips)
+  // Independent roots (the quadruped's four legs) are processed one after the other -- loads, RNEA
+  // passes, gradient sweep, park -- so that only one root's state is live at a time.  A robot with a
+  // single root runs this body once.
   JTrig<T> tr[N];
   T qv[N], qdv[N], qddv[N];
-  sfor<0, N>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    qv[j] = q[b * N + j];
-    qdv[j] = qd[b * N + j];
-    if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
-  });
+  T f[N][6], c[N];
+  T acc[N][N];
+  T v[N][6], a[N][6];
+  T dv[N][MAXDEPTH][6], da[N][MAXDEPTH][6];
+  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  auto load_group = [&](auto G) {
+    constexpr int g = decltype(G)::value;
+    sfor<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (grp_has(g, j)) {
+        qv[j] = q[b * N + j];
+        qdv[j] = qd[b * N + j];
+        if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
+      }
+    });
+  };
+  sfor<0, N>([&](auto Rt) {
+   constexpr int rt = decltype(Rt)::value;
+   if constexpr (grp_head(rt)) {
+   constexpr int row0 = grp_row0(rt);
+   constexpr int rows = grp_rows(rt);
+   T* my = tile + slot * GRAD_TS + (isqd ? N : 0) - row0 * GRAD_ROW;   // my[i * 2N + c], rows of this group
+  // All of a group's input loads are issued together and before its first sincos (whose
+  // range-reduction branch would otherwise fence each load behind the previous joint's trig: n
+  // serialized HBM round trips); the NEXT group's loads are issued before this group's passes, so
+  // their latency hides behind a whole group of arithmetic.
+  if constexpr (rt == grp_first()) load_group(Rt);
 #ifdef RBD_EXP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RBD_STAMP(1);
-  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (grp_has(rt, j)) tr[j] = make_trig<j>(qv[j]); });
+  if constexpr (grp_next(rt) >= 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
   RBD_STAMP(2);
 
   // ---- pass 1: RNEA forward + backward -> c and the ACCUMULATED forces f (:569-619) -----------
-  T f[N][6];
-  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   {
-    T v[N][6], a[N][6];
+    T v1[N][6], a1[N][6];
     sfor<0, N>([&](auto J) {
       constexpr int j = decltype(J)::value;
       constexpr int p = PARENT[j];
-      T xv[6], xa[6];
-      if constexpr (p < 0)
-        rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
-      else
-        rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
+      if constexpr (grp_has(rt, j)) {
+        T xv[6], xa[6];
+        if constexpr (p < 0)
+          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v1[j], a1[j], f[j]);
+        else
+          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v1[p], a1[p], xv, xa, v1[j], a1[j], f[j]);
+      }
     });
   }
-  T c[N];
   sfor_down<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int p = PARENT[j];
-    c[j] = S_dot<j>(f[j]);
-    if constexpr (p >= 0) {
-      T t[6];
-      xform_T<j>(tr[j], f[j], t);
-      sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+    if constexpr (grp_has(rt, j)) {
+      c[j] = S_dot<j>(f[j]);
+      if constexpr (p >= 0) {
+        T t[6];
+        xform_T<j>(tr[j], f[j], t);
+        sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+      }
     }
   });
   if (c_out != nullptr && !isqd && slot < nvalid) {
-    sfor<0, N>([&](auto J) { c_out[b * N + decltype(J)::value] = c[decltype(J)::value]; });
+    sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (grp_has(rt, j)) c_out[b * N + j] = c[j]; });
   }
 
   RBD_STAMP(3);
@@ -335,14 +403,11 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   // Column slot s of body j = its ancestor-or-self at depth s.  dv/da[j][s] are this lane's
   // derivative columns (dq columns on even lanes, dqd columns on odd lanes).  acc[i][c] collects
   // dc[i, c] for related (i, c); everything is statically indexed => registers.
-  T acc[N][N];
-  T* my = tile + slot * GRAD_TS + (isqd ? N : 0);   // LDS image of this lane's half rows: my[i * 2N + c]
-  T v[N][6], a[N][6];
-  T dv[N][MAXDEPTH][6], da[N][MAXDEPTH][6];
   sfor<0, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int p = PARENT[j];
     constexpr int d = DEPTH[j];
+    if constexpr (grp_has(rt, j)) {
     const JTrig<T> g{launder(tr[j].s), launder(tr[j].c)};
     const T qdj = launder(qdv[j]);
     const T qddj = HAS_QDD ? launder(qddv[j]) : T(0);
@@ -416,46 +481,52 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
         }
       });
     });
+    }  // grp_has(rt, j)
   });
 
+  // ---- this group is complete: finish its rows in the LDS image and stream them out -----------
   RBD_STAMP(4);
   if constexpr (FDG) {
-    // out[i][c] = - sum_k Minv[i][k] dc[k][c]; dc[k][c] is structurally zero for unrelated (k, c)
+    // out[i][c] = - sum_k Minv[i][k] dc[k][c]  (:1382-1383); Minv and dc are block-diagonal over groups
     __syncthreads();                       // mtile is complete (written by other lanes at the start)
     const T* mt = mtile + (slot < nvalid ? slot : 0) * (N * N);
     sfor<0, N>([&](auto C) {
       constexpr int cc = decltype(C)::value;
-      T colv[N];
-      sfor<0, N>([&](auto K) {
-        constexpr int k = decltype(K)::value;
-        if constexpr (related(k, cc)) colv[k] = acc[k][cc] + ((k == cc) ? sel(use_damping != 0 && isqd, T(DAMPING[k]), T(0)) : T(0));
-        else colv[k] = T(0);
-      });
-      sfor<0, N>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        T o = T(0);
+      if constexpr (!grp_has(rt, cc)) {
+        sfor<row0, row0 + rows>([&](auto I) { my[decltype(I)::value * GRAD_ROW + cc] = T(0); });
+      } else {
+        T colv[N];
         sfor<0, N>([&](auto K) {
           constexpr int k = decltype(K)::value;
-          if constexpr (related(k, cc)) o = fma_(-mt[i * N + k], colv[k], o);
+          if constexpr (related(k, cc)) colv[k] = acc[k][cc] + ((k == cc) ? sel(use_damping != 0 && isqd, T(DAMPING[k]), T(0)) : T(0));
+          else colv[k] = T(0);
         });
-        my[i * GRAD_ROW + cc] = o;
-      });
-    });
-  } else
-  // ---- park the accumulators in the LDS image of the output tile, stream it out coalesced -----
-  sfor<0, N>([&](auto I) {
-    sfor<0, N>([&](auto C) {
-      constexpr int i = decltype(I)::value, cc = decltype(C)::value;
-      if constexpr (!related(i, cc)) {
-        my[i * GRAD_ROW + cc] = T(0);                                       // structural zero
-      } else if constexpr (GRAD_ACC_IN_REGS) {
-        if constexpr (i == cc) my[i * GRAD_ROW + cc] = acc[i][cc] + sel(use_damping != 0 && isqd, T(DAMPING[i]), T(0));  // :1336-1341
-        else my[i * GRAD_ROW + cc] = acc[i][cc];
-      } else if constexpr (i == cc) {
-        my[i * GRAD_ROW + cc] += sel(use_damping != 0 && isqd, T(DAMPING[i]), T(0));
+        sfor<row0, row0 + rows>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          T o = T(0);
+          sfor<0, N>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (related(k, cc)) o = fma_(-mt[i * N + k], colv[k], o);
+          });
+          my[i * GRAD_ROW + cc] = o;
+        });
       }
     });
-  });
+  } else {
+    sfor<row0, row0 + rows>([&](auto I) {
+      sfor<0, N>([&](auto C) {
+        constexpr int i = decltype(I)::value, cc = decltype(C)::value;
+        if constexpr (!related(i, cc)) {
+          my[i * GRAD_ROW + cc] = T(0);                                     // structural zero
+        } else if constexpr (GRAD_ACC_IN_REGS) {
+          if constexpr (i == cc) my[i * GRAD_ROW + cc] = acc[i][cc] + sel(use_damping != 0 && isqd, T(DAMPING[i]), T(0));  // :1336-1341
+          else my[i * GRAD_ROW + cc] = acc[i][cc];
+        } else if constexpr (i == cc) {
+          my[i * GRAD_ROW + cc] += sel(use_damping != 0 && isqd, T(DAMPING[i]), T(0));
+        }
+      });
+    });
+  }
   __syncthreads();
   RBD_STAMP(5);
 #ifdef RBD_EXP_STAMPS
@@ -464,25 +535,34 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     c_out[cfg0 * N + 5] = (T)(float)(stamps[0] & 0xffffff);
   }
 #endif
-  T* gdst = dcdu + cfg0 * GRAD_TILE;
-  const int total = nvalid * GRAD_TILE;
-  constexpr int VE = 16 / sizeof(T);
-  if constexpr (GRAD_TS == GRAD_TILE && (CFGS * GRAD_TILE) % VE == 0) {
-    // LDS image == HBM image: 16-byte copies (block base is a multiple of CFGS * GRAD_TILE elements)
-    typedef T V __attribute__((ext_vector_type(VE)));
-    if (nvalid == CFGS) {
-      const V* src = reinterpret_cast<const V*>(tile);
-      V* dst = reinterpret_cast<V*>(gdst);
+  {
+    constexpr int RW = rows * GRAD_ROW;                         // elements of this group per configuration
+    T* gdst = dcdu + cfg0 * GRAD_TILE + row0 * GRAD_ROW;
+    constexpr int VE = 16 / sizeof(T);
+    bool done = false;
+    if constexpr (RW == GRAD_TILE && GRAD_TS == GRAD_TILE && (CFGS * GRAD_TILE) % VE == 0) {
+      // LDS image == HBM image: 16-byte copies (block base is a multiple of CFGS * GRAD_TILE elements)
+      typedef T V __attribute__((ext_vector_type(VE)));
+      if (nvalid == CFGS) {
+        const V* src = reinterpret_cast<const V*>(tile);
+        V* dst = reinterpret_cast<V*>(gdst);
 #pragma unroll 4
-      for (int g = lane; g < CFGS * GRAD_TILE / VE; g += NT) dst[g] = src[g];
-      return;
+        for (int g = lane; g < CFGS * GRAD_TILE / VE; g += NT) dst[g] = src[g];
+        done = true;
+      }
+    }
+    if (!done) {
+#pragma unroll 4
+      for (int g = lane; g < nvalid * RW; g += NT) {
+        const int cfg = g / RW;
+        const int rem = g - cfg * RW;
+        gdst[cfg * GRAD_TILE + rem] = tile[cfg * GRAD_TS + rem];
+      }
     }
   }
-#pragma unroll 4
-  for (int g = lane; g < total; g += NT) {
-    int cfg = g / GRAD_TILE;
-    gdst[g] = tile[g + cfg * (GRAD_TS - GRAD_TILE)];
-  }
+  if constexpr (GRAD_PER_ROOT && rows != N) __syncthreads();   // the next group reuses the tile
+   }  // grp_head(rt)
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
