@@ -565,6 +565,15 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   });
 }
 
+}  // namespace rbdk
+#include "rbd_idsva.h"
+namespace rbdk {
+#ifdef RBD_NO_IDSVA
+constexpr bool GRAD_USE_IDSVA = false;
+#else
+constexpr bool GRAD_USE_IDSVA = GRAD_IDSVA_OK;
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // minv: q -> Minv [B, n, n]                                                    (:630-806)
 //
@@ -928,8 +937,30 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
   if (B == 0) return 0;
   if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
-  if (qdd) return rnea_grad_launch1<T, true, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
-  return rnea_grad_launch1<T, false, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
+  if constexpr (rbdk::GRAD_USE_IDSVA) {
+    // one lane per configuration (rbd_idsva.h)
+    using namespace rbdk;
+    const int64_t blocks = (B + 63) / 64;
+    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+    const size_t lds = sizeof(T) * (size_t)64 * GRAD_TS;
+    if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
+    int rc;
+    if (qdd) {
+      auto k = rnea_grad_idsva_kernel<T, true>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+    } else {
+      auto k = rnea_grad_idsva_kernel<T, false>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
+    return 0;
+  } else {
+    if (qdd) return rnea_grad_launch1<T, true, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
+    return rnea_grad_launch1<T, false, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
+  }
 }
 
 template <class T>

@@ -204,7 +204,9 @@ def test_full_size_properties(name, B):
     # Minv (c - c0) = Minv H qdd = qdd
     back = torch.einsum("bij,bj->bi", Mi.double(), (c - c0).double())
     scale = qdd.abs().max().item()
-    assert (back - qdd.double()).abs().max().item() < (5e-4 if n < 30 else 5e-3) * scale
+    # fp32: c carries ~1e-6 relative rounding on gravity-sized torques; (c - c0) = H qdd is O(1), so the
+    # difference has ~5e-5 relative error, amplified by cond(Minv) ~ 1e2 (n = 7, 12) .. 1e3 (n = 30)
+    assert (back - qdd.double()).abs().max().item() < (3e-3 if n < 30 else 1e-2) * scale
     # dc_dqd independent of qdd
     d = (dc[:, :, n:] - dc0[:, :, n:]).abs().amax(dim=(1, 2)) / dc0[:, :, n:].abs().amax(dim=(1, 2)).clamp_min(1e-30)
     assert d.max().item() < 1e-5

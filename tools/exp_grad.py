@@ -11,9 +11,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    from rbdreference_amd import iiwa_like, pack_robot
+    from rbdreference_amd import builtin_robot, pack_robot
     from rbdreference_amd.build import build_model, lib_path
-    m = pack_robot(iiwa_like())
+    m = pack_robot(builtin_robot(os.environ.get("ROBOT", "iiwa_like")))
+    F64 = os.environ.get("DTYPE", "f32") == "f64"
     if sys.argv[1] == "build":
         from concurrent.futures import ThreadPoolExecutor
         specs = [a.split("=", 1) for a in sys.argv[2:]]
@@ -26,15 +27,17 @@ def main():
     base = lib_path(m)
     libs = [("base", base)] + sorted((os.path.basename(p).split(".")[-2], p) for p in glob.glob(base[:-3] + ".*.so"))
     rng = np.random.default_rng(0)
-    q = torch.tensor(rng.uniform(-np.pi, np.pi, (B, 7)), dtype=torch.float32, device="cuda")
-    qd = torch.tensor(rng.uniform(-1, 1, (B, 7)), dtype=torch.float32, device="cuda")
-    qdd = torch.tensor(rng.uniform(-1, 1, (B, 7)), dtype=torch.float32, device="cuda")
-    c = torch.empty((B, 7), dtype=torch.float32, device="cuda"); dc = torch.empty((B, 7, 14), dtype=torch.float32, device="cuda")
+    n = m.n
+    tdt = torch.float64 if F64 else torch.float32
+    q = torch.tensor(rng.uniform(-np.pi, np.pi, (B, n)), dtype=tdt, device="cuda")
+    qd = torch.tensor(rng.uniform(-1, 1, (B, n)), dtype=tdt, device="cuda")
+    qdd = torch.tensor(rng.uniform(-1, 1, (B, n)), dtype=tdt, device="cuda")
+    c = torch.empty((B, n), dtype=tdt, device="cuda"); dc = torch.empty((B, n, 2 * n), dtype=tdt, device="cuda")
     fns = []
     for tag, p in libs:
         L = ctypes.CDLL(p)
-        f = L.rbd_rnea_grad_f32
-        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 3
+        f = L.rbd_rnea_grad_f64 if F64 else L.rbd_rnea_grad_f32
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_double if F64 else ctypes.c_float, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 3
         fns.append((tag, f))
     st = torch.cuda.current_stream().cuda_stream
     res = {t: [] for t, _ in fns}
