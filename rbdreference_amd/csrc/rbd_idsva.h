@@ -390,6 +390,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
           my[jj * GRAD_ROW + j] = dot6(Sv[jj], t3);
           my[jj * GRAD_ROW + N + j] = dot6(Sv[jj], t2);
         }
+
       });
       // structural zeros of row j / column j: bodies of other groups
       sfor<0, N>([&](auto C_) {
