@@ -71,7 +71,8 @@ int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, doub
  *   Minv : [B, n, n].  output_dense != 0: symmetric matrix (:799-804).  output_dense == 0: upper
  *   triangle as the reference defines it, strict lower triangle ZERO (the reference leaves
  *   by-products of its forward pass there, :771; documented deviation).
- *   workspace: device scratch of at least rbd_minv_workspace_bytes(B, sizeof(T)) bytes.        */
+ *   workspace: device scratch of at least rbd_minv_workspace_bytes(B, sizeof(T)) bytes, 16-byte
+ *   aligned (0 bytes -- and then ignored -- for robots that use the fused one-lane kernel).       */
 size_t rbd_minv_workspace_bytes(int64_t B, int elem_size);
 int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void* workspace,
                  size_t workspace_bytes, void* stream);

@@ -825,6 +825,16 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
 }
 
 }  // namespace rbdk
+#include "rbd_minv_lane.h"
+namespace rbdk {
+#ifdef RBD_NO_MINV_LANE
+constexpr bool MINV_USE_LANE = false;
+#else
+constexpr bool MINV_USE_LANE = MINV_LANE_OK;
+#endif
+// scalars of HBM workspace per configuration (none for the fused one-lane kernel)
+constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
+}  // namespace rbdk
 
 // =============================================================================================
 // C-ABI (include/rbd_hip.h)
@@ -970,6 +980,19 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
   if (!q || (!Minv && !qdd)) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  if constexpr (MINV_USE_LANE) {
+    // fused one-lane-per-configuration kernel (rbd_minv_lane.h): no workspace
+    const int64_t blocks = (B + 63) / 64;
+    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
+    const size_t lds = sizeof(T) * (size_t)64 * MINV_LANE_TS;
+    auto k = minv_lane_kernel<T>;
+    int rc;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, (long long)B, output_dense, Minv, u, cbias, qdd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_minv launch");
+    return 0;
+  } else {
   const size_t need = (size_t)B * N * MINV_WS * sizeof(T);
   if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
@@ -988,6 +1011,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase B launch");
   return 0;
+  }
 }
 
 // ---- forward dynamics: compositions of the three kernels with fused epilogues ----
@@ -998,7 +1022,7 @@ struct FdWorkspace {
   explicit FdWorkspace(int64_t B) {
     using namespace rbdk;
     size_t o = 0;
-    off_minv_ws = o; o += align16((size_t)B * N * MINV_WS * sizeof(T));
+    off_minv_ws = o; o += align16((size_t)B * MINV_WS_PER_CFG * sizeof(T));
     off_c = o;       o += align16((size_t)B * N * sizeof(T));
     off_minv = o;    o += align16((size_t)B * N * N * sizeof(T));
     off_qdd = o;     o += align16((size_t)B * N * sizeof(T));
@@ -1036,7 +1060,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics rnea launch");
   }
   // qdd = Minv (u - c) (:1373-1374); Minv itself is kept only when the gradient needs it
-  if ((rc = minv_launch<T>(q, B, 1, want_grad ? Mi : nullptr, w + L.off_minv_ws, (size_t)B * N * MINV_WS * sizeof(T),
+  if ((rc = minv_launch<T>(q, B, 1, want_grad ? Mi : nullptr, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T),
                            stream, u, c, qdd_buf)) != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
@@ -1078,7 +1102,7 @@ int rbd_model_info(rbd_model_info_t* out) {
 }
 size_t rbd_minv_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
-  return (size_t)B * rbdm::N * rbdk::MINV_WS * (size_t)elem_size;
+  return (size_t)B * rbdk::MINV_WS_PER_CFG * (size_t)elem_size;
 }
 size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0) return 0;

@@ -1,0 +1,164 @@
+// rbd_minv_lane.h -- minv (and the forward-dynamics product) as ONE fused kernel, one configuration
+// per lane, for robots whose root subtrees ("groups") have at most 8 bodies.
+//
+// The two-phase kernels (minv_ia_kernel + minv_cols_kernel) hand {U, 1/D, sin, cos} per body through
+// an HBM workspace of 48 B x n per configuration -- for a 7-DoF arm that round trip (336 B written,
+// 336 B read) is more than the 224 B of q + Minv the algorithm has to move, and two thirds of the
+// measured time.  Here the articulated-inertia recursion (RBDReference.py:697-700, :728-733) and
+// the per-column backward / forward sweeps (:702-726, :771-776) of a configuration run in the same
+// lane, U / D stay in registers, columns are processed one after the other (each column only visits
+// the bodies on its own root path in the backward sweep and the bodies with index <= its own in the
+// forward sweep -- all resolved at compile time), and a finished column goes to the LDS image of
+// the output tile.  Independent roots are processed as groups exactly as in rnea_grad_kernel:
+// Minv is block-diagonal over groups, so other groups' columns are structural zeros.
+#pragma once
+#include "rbd_spatial.h"
+
+namespace rbdk {
+
+constexpr bool MINV_LANE_OK = GRAD_PER_ROOT && grad_max_rows() <= 8;
+// LDS stride between configurations (odd => conflict-free per-lane rows)
+constexpr int MINV_LANE_TS = (grad_max_rows() * N) | 1;
+
+template <class T>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void minv_lane_kernel(const T* __restrict__ q, long long B, int dense,
+                                                                              T* __restrict__ Minv, const T* __restrict__ u_in,
+                                                                              const T* __restrict__ c_in, T* __restrict__ qdd_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const long long cfg0 = (long long)blockIdx.x * 64;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < 64 ? (int)rem : 64;
+  const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
+  const bool fd = qdd_out != nullptr;
+
+  JTrig<T> tr[N];
+  T qv[N];
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; qv[j] = q[b * N + j]; });
+  T tau[N], qacc[N];
+  if (fd) {
+    sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tau[j] = u_in[b * N + j] - c_in[b * N + j]; qacc[j] = T(0); });
+  } else {
+    sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tau[j] = T(0); qacc[j] = T(0); });
+  }
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
+
+  T U[N][6], Dinv[N];
+  sfor<0, N>([&](auto Rt) {
+   constexpr int rt = decltype(Rt)::value;
+   if constexpr (grp_head(rt)) {
+    constexpr int row0 = grp_row0(rt);
+    constexpr int rows = grp_rows(rt);
+    T* my = tile + lane * MINV_LANE_TS - row0 * N;     // my[i * N + c], rows of this group
+    // ---- articulated inertias of the group (:662, :697-700, :728-733) ---------------------------
+    {
+      T IA[N][6][6];
+      sfor<row0, row0 + rows>([&](auto J) {
+        sfor<0, 6>([&](auto R) {
+          sfor<0, 6>([&](auto C) {
+            constexpr int j = decltype(J)::value, r = decltype(R)::value, c = decltype(C)::value;
+            IA[j][r][c] = T(IM[j][r * 6 + c]);
+          });
+        });
+      });
+      sfor_down<row0, row0 + rows>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int p = PARENT[i];
+        constexpr int si = s_index(i);
+        sfor<0, 6>([&](auto R) { U[i][decltype(R)::value] = IA[i][decltype(R)::value][si]; });   // U = IA S
+        Dinv[i] = T(1) / U[i][si];                                                                // 1 / (S^T U)
+        if constexpr (p >= 0) {
+          T A[6][6];   // A = X^T Ia, Ia = IA - U U^T / D
+          sfor<0, 6>([&](auto C) {
+            constexpr int c = decltype(C)::value;
+            T col[6], y[6];
+            const T uc = U[i][c] * Dinv[i];
+            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[i][r], uc, IA[i][r][c]); });
+            xform_T<i>(tr[i], col, y);
+            sfor<0, 6>([&](auto R) { A[decltype(R)::value][c] = y[decltype(R)::value]; });
+          });
+          sfor<0, 6>([&](auto R) {   // IA_p += (A X): row r of A X = X^T A[r][:]^T
+            constexpr int r = decltype(R)::value;
+            T y[6];
+            xform_T<i>(tr[i], A[r], y);
+            sfor<0, 6>([&](auto C) { IA[p][r][decltype(C)::value] += y[decltype(C)::value]; });
+          });
+        }
+      });
+    }
+    // ---- one column of Minv at a time ----------------------------------------------------------------
+    sfor<row0, row0 + rows>([&](auto JC) {
+      constexpr int jc = decltype(JC)::value;
+      T mcol[N];
+      sfor<row0, jc + 1>([&](auto I) { mcol[decltype(I)::value] = T(0); });
+      // backward sweep along the root path of jc (:700-726)
+      T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+      sfor_down<row0, jc + 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (is_anc_or_self(i, jc)) {
+          constexpr int p = PARENT[i];
+          T m;
+          if constexpr (i == jc) m = Dinv[i];
+          else m = -(Dinv[i] * S_dot<i>(Fj));
+          mcol[i] = m;
+          if constexpr (p >= 0) {
+            T t[6], y[6];
+            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = (i == jc) ? U[i][r] * m : fma_(U[i][r], m, Fj[r]); });
+            xform_T<i>(tr[i], t, y);
+            sfor<0, 6>([&](auto R) { Fj[decltype(R)::value] = y[decltype(R)::value]; });
+          }
+        }
+      });
+      // forward sweep over the bodies i <= jc of the group (:760-781)
+      T Ff[N][6];
+      sfor<row0, jc + 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int p = PARENT[i];
+        constexpr int si = s_index(i);
+        if constexpr (p < 0) {
+          sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
+          Ff[i][si] = mcol[i];
+        } else {
+          xform<i>(tr[i], Ff[p], Ff[i]);
+          const T m = fma_(-Dinv[i], dot6(U[i], Ff[i]), mcol[i]);
+          mcol[i] = m;
+          Ff[i][si] += m;
+        }
+      });
+      // column jc is final for rows i <= jc: LDS image (with the mirror, :799-804) and Minv (u - c)
+      sfor<row0, jc + 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        my[i * N + jc] = mcol[i];
+        if constexpr (i < jc) my[jc * N + i] = sel(dense != 0, mcol[i], T(0));
+        qacc[i] = fma_(mcol[i], tau[jc], qacc[i]);
+        if constexpr (i < jc) qacc[jc] = fma_(mcol[i], tau[i], qacc[jc]);
+      });
+    });
+    // columns of other groups are structural zeros
+    sfor<row0, row0 + rows>([&](auto I) {
+      sfor<0, N>([&](auto C) {
+        constexpr int i = decltype(I)::value, c = decltype(C)::value;
+        if constexpr (!grp_has(rt, c)) my[i * N + c] = T(0);
+      });
+    });
+    if (fd && lane < nvalid) {
+      sfor<row0, row0 + rows>([&](auto I) { constexpr int i = decltype(I)::value; qdd_out[b * N + i] = qacc[i]; });
+    }
+    if (Minv != nullptr) {
+      __syncthreads();
+      constexpr int RW = rows * N;
+      T* gdst = Minv + cfg0 * (N * N) + row0 * N;
+#pragma unroll 4
+      for (int g = lane; g < nvalid * RW; g += 64) {
+        const int cfg = g / RW;
+        const int rem2 = g - cfg * RW;
+        gdst[cfg * (N * N) + rem2] = tile[cfg * MINV_LANE_TS + rem2];
+      }
+      if constexpr (rows != N) __syncthreads();
+    }
+   }
+  });
+}
+
+}  // namespace rbdk

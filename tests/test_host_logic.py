@@ -95,8 +95,11 @@ def test_capi_library_builds_loads_and_exports_every_symbol():
     assert L.rbd_rnea_f32(None, None, None, -9.81, 4, None, None, None, None, None) == -1
     assert b"non-null" in L.rbd_last_error()
     assert L.rbd_rnea_grad_f64(1, 1, None, -9.81, 0, -5, None, 1, None) == -1
-    assert L.rbd_minv_f32(1, 4, 1, 1, None, 0, None) == -3
-    assert L.rbd_minv_workspace_bytes(10, 4) == 10 * 6 * 12 * 4
+    wsb = L.rbd_minv_workspace_bytes(10, 4)
+    assert wsb in (0, 10 * 6 * 12 * 4)          # 0: fused one-lane minv kernel (no workspace)
+    if wsb:
+        assert L.rbd_minv_f32(1, 4, 1, 1, None, 0, None) == -3
+    assert L.rbd_minv_f32(1, 4, 1, None, None, 0, None) == -1
     assert L.rbd_minv_workspace_bytes(10, 2) == 0
     assert L.rbd_rnea_f32(None, None, None, -9.81, 0, None, None, None, None, None) == 0   # B = 0: no-op
     assert L.rbd_abi_version() == 1
