@@ -59,6 +59,16 @@ int rbd_rnea_f32(const float* q, const float* qd, const float* qdd, float gravit
 int rbd_rnea_f64(const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
                  double* c, double* v, double* a, double* f, void* stream);
 
+/* Per-pass surface the reference designates for accelerator testing (README.md:19):
+ * RBDReference.rnea_fpass(q, qd, qdd=None, GRAVITY) -> (v, a, f) with f LOCAL  (RBDReference.py:559-598)
+ * RBDReference.rnea_bpass(q, f) -> (c, f): accumulates child forces into f IN PLACE (RBDReference.py:600-621) */
+int rbd_rnea_fpass_f32(const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
+                       float* v, float* a, float* f, void* stream);
+int rbd_rnea_fpass_f64(const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
+                       double* v, double* a, double* f, void* stream);
+int rbd_rnea_bpass_f32(const float* q, float* f, int64_t B, float* c, void* stream);
+int rbd_rnea_bpass_f64(const double* q, double* f, int64_t B, double* c, void* stream);
+
 /* RBDReference.rnea_grad(q, qd, qdd=None, GRAVITY, USE_VELOCITY_DAMPING)   (RBDReference.py:1345-1368)
  *   dc_du : [B, n, 2n] = [dc_dq | dc_dqd]  (np.hstack, :1367)
  *   c     : [B, n] or NULL -- the bias force the reference computes on the way (:1353) and drops. */

@@ -20,6 +20,7 @@ RBD_ERR_ARG, RBD_ERR_UNSUPPORTED, RBD_ERR_WORKSPACE = -1, -2, -3
 EXPORTED_SYMBOLS = [
     "rbd_abi_version", "rbd_last_error", "rbd_model_info",
     "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
+    "rbd_rnea_fpass_f32", "rbd_rnea_fpass_f64", "rbd_rnea_bpass_f32", "rbd_rnea_bpass_f64",
     "rbd_minv_workspace_bytes", "rbd_minv_f32", "rbd_minv_f64",
     "rbd_fd_workspace_bytes", "rbd_forward_dynamics_f32", "rbd_forward_dynamics_f64",
     "rbd_forward_dynamics_grad_f32", "rbd_forward_dynamics_grad_f64",
@@ -51,6 +52,12 @@ def _declare(lib):
         f.restype = c_int
         f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_void_p,
                       c_void_p, c_void_p]
+        f = getattr(lib, f"rbd_rnea_fpass_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        f = getattr(lib, f"rbd_rnea_bpass_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
         f = getattr(lib, f"rbd_rnea_grad_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int, c_int64, c_void_p, c_void_p, c_void_p]

@@ -108,6 +108,51 @@ class RBDReference:
             return self._ret(c, unb, is_np), None, None, None
         return tuple(self._ret(t, unb, is_np) for t in (c, v, a, f))
 
+    def rnea_fpass(self, q, qd, qdd=None, GRAVITY=-9.81):
+        """RBDReference.rnea_fpass (``RBDReference.py:559-598``) -> ``(v, a, f)`` with the LOCAL body
+        forces (no backward accumulation) -- the per-pass surface of ``README.md:19``."""
+        (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
+        B = q.shape[0]
+        with torch.cuda.device(dev):
+            v = torch.empty((B, 6, self.n), device=dev, dtype=dt)
+            a = torch.empty_like(v)
+            f = torch.empty_like(v)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_fpass", dt)(
+                self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY), B,
+                self._ptr(v), self._ptr(a), self._ptr(f), st))
+        return tuple(self._ret(t, unb, is_np) for t in (v, a, f))
+
+    def rnea_bpass(self, q, f):
+        """RBDReference.rnea_bpass (``RBDReference.py:600-621``) -> ``(c, f)``.  Like the reference it
+        accumulates into ``f`` IN PLACE when ``f`` is a contiguous device tensor (``:619``) and
+        returns that same tensor; numpy input gets a new array back."""
+        (q,), unb, is_np, dev, dt = self._prep(q)
+        B = q.shape[0]
+        if isinstance(f, torch.Tensor):
+            if is_np or f.device != dev or f.dtype != dt:
+                raise TypeError("f must share device and dtype with q")
+            ft = f[None] if unb else f
+            if ft.shape != (B, 6, self.n):
+                raise ValueError(f"f must have shape [B, 6, {self.n}]")
+            fc = ft if ft.is_contiguous() else ft.contiguous()
+        else:
+            fa = np.asarray(f, dtype=np.float64)
+            fa = fa[None] if unb else fa
+            if fa.shape != (B, 6, self.n):
+                raise ValueError(f"f must have shape [B, 6, {self.n}]")
+            fc = torch.as_tensor(fa, device=dev).contiguous()
+            ft = None
+        with torch.cuda.device(dev):
+            c = torch.empty((B, self.n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_bpass", dt)(self._ptr(q), self._ptr(fc), B, self._ptr(c), st))
+        if ft is not None and fc is not ft:
+            ft.copy_(fc)
+        if ft is not None:
+            return self._ret(c, unb, is_np), f
+        return self._ret(c, unb, is_np), self._ret(fc, unb, is_np)
+
     def rnea_grad(self, q, qd, qdd=None, GRAVITY=-9.81, USE_VELOCITY_DAMPING=False,
                   return_c: bool = False):
         """RBDReference.rnea_grad (``RBDReference.py:1345-1368``) -> ``dc_du = [dc_dq | dc_dqd]``,

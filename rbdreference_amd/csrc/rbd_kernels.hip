@@ -91,7 +91,8 @@ template <class T, bool HAS_QDD, bool WITH_VAF>
 __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                   const T* __restrict__ qdd, T grav, long long B,
                                                   T* __restrict__ c_out, T* __restrict__ v_out,
-                                                  T* __restrict__ a_out, T* __restrict__ f_out) {
+                                                  T* __restrict__ a_out, T* __restrict__ f_out, int fpass_only) {
+  // fpass_only != 0: the reference's rnea_fpass (:559-598) -- f stays LOCAL, no backward pass, no c
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
@@ -161,16 +162,19 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
   }
   // backward pass (:607-619)
   T c[N];
-  sfor_down<0, N>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    constexpr int p = PARENT[j];
-    c[j] = S_dot<j>(f[j]);
-    if constexpr (p >= 0) {
-      T t[6];
-      xform_T<j>(tr[j], f[j], t);
-      sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
-    }
-  });
+  sfor<0, N>([&](auto J) { c[decltype(J)::value] = T(0); });
+  if (!fpass_only) {
+    sfor_down<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      c[j] = S_dot<j>(f[j]);
+      if constexpr (p >= 0) {
+        T t[6];
+        xform_T<j>(tr[j], f[j], t);
+        sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+      }
+    });
+  }
 
   if constexpr (WITH_VAF) {
     // reference layout (6, NB) per configuration: element [r][i]
@@ -184,6 +188,43 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
     sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
     staged_store<K6>(lds, tmp, f_out + cfg0 * K6, lane, nvalid);
   }
+  if (c_out != nullptr) staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
+}
+
+// rnea_bpass (:600-621): f [B,6,n] in -> c [B,n] and f accumulated IN PLACE, as the reference does.
+// (debug / per-pass surface of README.md:19; one configuration per lane, plain strided reads)
+template <class T>
+__global__ __launch_bounds__(64) void rnea_bpass_kernel(const T* __restrict__ q, T* __restrict__ f_io, long long B,
+                                                        T* __restrict__ c_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const long long cfg0 = (long long)blockIdx.x * 64;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < 64 ? (int)rem : 64;
+  const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
+  constexpr int K6 = 6 * N;
+  JTrig<T> tr[N];
+  T qv[N];
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; qv[j] = q[b * N + j]; });
+  T f[N][6];
+  sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; f[j][r] = f_io[b * K6 + r * N + j]; }); });
+  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
+  T c[N];
+  sfor_down<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    c[j] = S_dot<j>(f[j]);
+    if constexpr (p >= 0) {
+      T t[6];
+      xform_T<j>(tr[j], f[j], t);
+      sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+    }
+  });
+  __syncthreads();   // every lane has read its f before the tile is written back
+  T tmp[K6];
+  sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
+  staged_store<K6>(lds, tmp, f_io + cfg0 * K6, lane, nvalid);
   staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
 }
 
@@ -892,11 +933,12 @@ int ensure_lds(K kernel, size_t bytes) {
 
 template <class T>
 int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f,
-                void* stream) {
+                void* stream, int fpass_only = 0) {
   using namespace rbdk;
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea: B < 0");
   if (B == 0) return 0;
-  if (!q || !qd || !c) return fail(RBD_ERR_ARG, "rbd_rnea: q, qd and c must be non-null");
+  if (!q || !qd || (!c && !fpass_only)) return fail(RBD_ERR_ARG, "rbd_rnea: q, qd and c must be non-null");
+  if (fpass_only && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea_fpass: v, a, f must be non-null");
   const bool vaf = v || a || f;
   if (vaf && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea: v, a, f must be all null or all non-null");
   const int64_t blocks = (B + 63) / 64;
@@ -910,13 +952,31 @@ int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* 
     auto k = rnea_kernel<T, HQ, VAF>;                                                              \
     if ((rc = ensure_lds(k, LDS)) != 0) return rc;                                                 \
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), LDS, s, q, qd, qdd, gravity,           \
-                       (long long)B, c, v, a, f);                                                  \
+                       (long long)B, c, v, a, f, fpass_only);                                      \
   } while (0)
   if (qdd) { if (vaf) RBD_LAUNCH_RNEA(true, true, lds); else RBD_LAUNCH_RNEA(true, false, lds_c); }
   else     { if (vaf) RBD_LAUNCH_RNEA(false, true, lds); else RBD_LAUNCH_RNEA(false, false, lds_c); }
 #undef RBD_LAUNCH_RNEA
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_rnea launch");
+  return 0;
+}
+
+template <class T>
+int rnea_bpass_launch(const T* q, T* f, int64_t B, T* c, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_bpass: B < 0");
+  if (B == 0) return 0;
+  if (!q || !f || !c) return fail(RBD_ERR_ARG, "rbd_rnea_bpass: q, f and c must be non-null");
+  const int64_t blocks = (B + 63) / 64;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_bpass: B too large");
+  const size_t lds = sizeof(T) * 64 * (size_t)odd_pad<6 * N>();
+  auto k = rnea_bpass_kernel<T>;
+  int rc;
+  if ((rc = ensure_lds(k, lds)) != 0) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, f, (long long)B, c);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_rnea_bpass launch");
   return 0;
 }
 
@@ -1055,7 +1115,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     const size_t lds = rnea_lds_bytes<T>(false);
     if ((rc = ensure_lds(k, lds)) != 0) return rc;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)nullptr, gravity,
-                       (long long)B, c, (T*)nullptr, (T*)nullptr, (T*)nullptr);
+                       (long long)B, c, (T*)nullptr, (T*)nullptr, (T*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics rnea launch");
   }
@@ -1115,6 +1175,24 @@ size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {
 int rbd_rnea_f32(const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
                  float* c, float* v, float* a, float* f, void* stream) {
   return rnea_launch<float>(q, qd, qdd, gravity, B, c, v, a, f, stream);
+}
+#endif
+#ifdef RBD_TU_RNEA_F32
+int rbd_rnea_fpass_f32(const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
+                       float* v, float* a, float* f, void* stream) {
+  return rnea_launch<float>(q, qd, qdd, gravity, B, nullptr, v, a, f, stream, 1);
+}
+int rbd_rnea_bpass_f32(const float* q, float* f, int64_t B, float* c, void* stream) {
+  return rnea_bpass_launch<float>(q, f, B, c, stream);
+}
+#endif
+#ifdef RBD_TU_RNEA_F64
+int rbd_rnea_fpass_f64(const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
+                       double* v, double* a, double* f, void* stream) {
+  return rnea_launch<double>(q, qd, qdd, gravity, B, nullptr, v, a, f, stream, 1);
+}
+int rbd_rnea_bpass_f64(const double* q, double* f, int64_t B, double* c, void* stream) {
+  return rnea_bpass_launch<double>(q, f, B, c, stream);
 }
 #endif
 #ifdef RBD_TU_RNEA_F64

@@ -257,3 +257,22 @@ def test_forward_dynamics_round_trip_full_size():
     assert isinstance(out, np.ndarray) and rel_err_rows(out[None], g["fd_qdd"][1:2]) < 1e-9
     a, b = rbd.forward_dynamics_grad(g["q"][1], g["qd"][1], g["qdd"][1])
     assert a.shape == (7, 7) and rel_err_rows(np.ascontiguousarray(b)[None], g["fd_dqd"][1:2]) < 1e-9
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_rnea_per_pass_surface(name, prec):
+    """rnea_fpass / rnea_bpass (README.md:19's accelerator-testing surface) against the reference's
+    per-pass outputs; rnea_bpass mutates its f argument in place and returns it (RBDReference.py:619)."""
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    v, a, f = rbd.rnea_fpass(q, qd, qdd)
+    check("fpass v", v, g["fpass_v"], tol); check("fpass a", a, g["fpass_a"], tol)
+    check("fpass f (local)", f, g["fpass_f"], tol)
+    (f_in,) = dev_tensors(dt, g["fpass_f"])
+    c, f_ret = rbd.rnea_bpass(q, f_in)
+    assert f_ret is f_in
+    check("bpass c", c, g["c"], tol); check("bpass f (accumulated, in place)", f_in, g["f_acc"], tol)
+    c1, f1 = rbd.rnea_bpass(g["q"][0], g["fpass_f"][0])                 # numpy, unbatched
+    assert isinstance(f1, np.ndarray) and f1.shape == (6, rbd.n)
+    assert rel_err_rows(f1[None], g["f_acc"][:1]) < TOL64 and rel_err_rows(c1[None], g["c"][:1]) < TOL64
