@@ -21,18 +21,36 @@ namespace rbdk {
 
 // ---------------------------------------------------------------------------------------------
 // LDS-staged coalesced store: each of the block's 64 lanes holds K values of its configuration
-// (global layout [cfg][K], row-major).  Lanes park them in LDS (row stride KP, odd => conflict
-// free), then the wave streams the tile out linearly, 64 consecutive elements per instruction.
+// (global layout [cfg][K], row-major).  Lanes park them in LDS with row stride odd_pad<K>(), then
+// the wave streams the tile out.  When K itself gives at most 4-way bank conflicts on the per-lane
+// 4-byte writes (2-way is free, 4-way costs 2x on ds_write_b32) the tile is left UNPADDED: the LDS
+// image then equals the HBM image and leaves as flat 16-byte copies (one ds_read_b128 + one
+// global_store_dwordx4 per 4 elements instead of ~10 instructions per element).  Otherwise the stride
+// is padded to an odd number (conflict-free writes, element-wise read-out).
 // ---------------------------------------------------------------------------------------------
+constexpr int gcd32(int k) {
+  int g = 32;
+  while (k % g != 0) g /= 2;
+  return g;
+}
 template <int K>
-constexpr int odd_pad() { return (K % 2 == 0) ? K + 1 : K; }
+constexpr int odd_pad() { return gcd32(K) <= 4 && K % 4 == 0 ? K : gcd32(K) == 2 ? K : (K % 2 == 0) ? K + 1 : K; }
 
+// stream a [64][odd_pad<K>]-strided LDS tile out as [nvalid][K] rows
 template <int K, class T>
-RBD_DEV void staged_store(T* lds, const T (&vals)[K], T* gdst, int lane, int nvalid) {
+RBD_DEV void flush_tile(const T* lds, T* gdst, int lane, int nvalid) {
   constexpr int KP = odd_pad<K>();
-  __syncthreads();  // previous users of `lds` are done
-  sfor<0, K>([&](auto I) { lds[lane * KP + decltype(I)::value] = vals[decltype(I)::value]; });
-  __syncthreads();
+  constexpr int VE = 16 / sizeof(T);
+  if constexpr (KP == K && (64 * K) % VE == 0) {
+    if (nvalid == 64) {
+      typedef T V __attribute__((ext_vector_type(VE)));
+      const V* src = reinterpret_cast<const V*>(lds);
+      V* dst = reinterpret_cast<V*>(gdst);
+#pragma unroll 4
+      for (int g = lane; g < 64 * K / VE; g += 64) dst[g] = src[g];
+      return;
+    }
+  }
   const int total = nvalid * K;
 #pragma unroll 4
   for (int g = lane; g < total; g += 64) {
@@ -40,6 +58,15 @@ RBD_DEV void staged_store(T* lds, const T (&vals)[K], T* gdst, int lane, int nva
     int r = g - cfg * K;
     gdst[g] = lds[cfg * KP + r];
   }
+}
+
+template <int K, class T>
+RBD_DEV void staged_store(T* lds, const T (&vals)[K], T* gdst, int lane, int nvalid) {
+  constexpr int KP = odd_pad<K>();
+  __syncthreads();  // previous users of `lds` are done
+  sfor<0, K>([&](auto I) { lds[lane * KP + decltype(I)::value] = vals[decltype(I)::value]; });
+  __syncthreads();
+  flush_tile<K>(lds, gdst, lane, nvalid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -72,19 +99,6 @@ constexpr size_t rnea_lds_bytes(bool vaf) {
   if (!vaf) return sizeof(T) * 64 * (size_t)odd_pad<N>();
   const size_t one = sizeof(T) * 64 * (size_t)odd_pad<6 * N>();
   return (RNEA_PARK_VA && rnea_two_tiles<T>()) ? 2 * one : one;
-}
-
-// stream a [64][KP]-strided LDS tile out as [nvalid][K] rows
-template <int K, class T>
-RBD_DEV void flush_tile(const T* lds, T* gdst, int lane, int nvalid) {
-  constexpr int KP = odd_pad<K>();
-  const int total = nvalid * K;
-#pragma unroll 4
-  for (int g = lane; g < total; g += 64) {
-    int cfg = g / K;
-    int r = g - cfg * K;
-    gdst[g] = lds[cfg * KP + r];
-  }
 }
 
 template <class T, bool HAS_QDD, bool WITH_VAF>
