@@ -89,6 +89,10 @@ int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void*
 int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* RBDReference.crba(q)  (fixed-base branch, RBDReference.py:1091-1124): joint-space inertia H [B, n, n]. */
+int rbd_crba_f32(const float* q, int64_t B, float* H, void* stream);
+int rbd_crba_f64(const double* q, int64_t B, double* H, void* stream);
+
 /* RBDReference.forward_dynamics(q, qd, u)                 (RBDReference.py:1371-1374)
  *   qdd = minv(q) @ (u - rnea(q, qd)[0])        u, qdd : [B, n]
  * RBDReference.forward_dynamics_grad(q, qd, u)            (RBDReference.py:1376-1384)

@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
     "rbd_rnea_fpass_f32", "rbd_rnea_fpass_f64", "rbd_rnea_bpass_f32", "rbd_rnea_bpass_f64",
     "rbd_minv_workspace_bytes", "rbd_minv_f32", "rbd_minv_f64",
+    "rbd_crba_f32", "rbd_crba_f64",
     "rbd_fd_workspace_bytes", "rbd_forward_dynamics_f32", "rbd_forward_dynamics_f64",
     "rbd_forward_dynamics_grad_f32", "rbd_forward_dynamics_grad_f64",
 ]
@@ -64,6 +65,9 @@ def _declare(lib):
         f = getattr(lib, f"rbd_minv_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        f = getattr(lib, f"rbd_crba_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
         f = getattr(lib, f"rbd_forward_dynamics_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]

@@ -187,6 +187,17 @@ class RBDReference:
                 self._ptr(q), B, 1 if output_dense else 0, self._ptr(M), ws.data_ptr(), wsb, st))
         return self._ret(M, unb, is_np)
 
+    def crba(self, q):
+        """RBDReference.crba (fixed-base branch, ``RBDReference.py:1091-1124``) -> joint-space inertia
+        ``H``, ``(n, n)`` per configuration."""
+        (q,), unb, is_np, dev, dt = self._prep(q)
+        B = q.shape[0]
+        with torch.cuda.device(dev):
+            H = torch.empty((B, self.n, self.n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_crba", dt)(self._ptr(q), B, self._ptr(H), st))
+        return self._ret(H, unb, is_np)
+
     # ---- next row of SURVEY.md §8f: forward dynamics on top of the three kernels --------------
     def _fd(self, q, qd, u, GRAVITY, want_grad):
         (q, qd, u), unb, is_np, dev, dt = self._prep(q, qd, u)

@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
 
 }  // namespace rbdk
 #include "rbd_minv_lane.h"
+#include "rbd_crba.h"
 namespace rbdk {
 #ifdef RBD_NO_MINV_LANE
 constexpr bool MINV_USE_LANE = false;
@@ -1088,6 +1089,24 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   }
 }
 
+template <class T>
+int crba_launch(const T* q, int64_t B, T* H, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_crba: B < 0");
+  if (B == 0) return 0;
+  if (!q || !H) return fail(RBD_ERR_ARG, "rbd_crba: q and H must be non-null");
+  const int64_t blocks = (B + 63) / 64;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_crba: B too large");
+  const size_t lds = crba_tile_fits<T>() ? sizeof(T) * (size_t)64 * CRBA_TS : 0;
+  auto k = crba_kernel<T>;
+  int rc;
+  if ((rc = ensure_lds(k, lds)) != 0) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, (long long)B, H);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_crba launch");
+  return 0;
+}
+
 // ---- forward dynamics: compositions of the three kernels with fused epilogues ----
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 template <class T>
@@ -1226,6 +1245,12 @@ int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, doub
                       int use_damping, int64_t B, double* c, double* dc_du, void* stream) {
   return rnea_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
 }
+#endif
+#ifdef RBD_TU_MINV_F32
+int rbd_crba_f32(const float* q, int64_t B, float* H, void* stream) { return crba_launch<float>(q, B, H, stream); }
+#endif
+#ifdef RBD_TU_MINV_F64
+int rbd_crba_f64(const double* q, int64_t B, double* H, void* stream) { return crba_launch<double>(q, B, H, stream); }
 #endif
 #ifdef RBD_TU_MINV_F32
 int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void* workspace,

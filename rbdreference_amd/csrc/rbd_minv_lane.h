@@ -149,11 +149,25 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void minv_lane_kernel(c
       __syncthreads();
       constexpr int RW = rows * N;
       T* gdst = Minv + cfg0 * (N * N) + row0 * N;
+      constexpr int VE = 16 / sizeof(T);
+      bool done = false;
+      if constexpr (RW == N * N && MINV_LANE_TS == N * N && (64 * N * N) % VE == 0) {
+        if (nvalid == 64) {     // LDS image == HBM image: flat 16-byte copies
+          typedef T V __attribute__((ext_vector_type(VE)));
+          const V* src = reinterpret_cast<const V*>(tile);
+          V* dst = reinterpret_cast<V*>(gdst);
 #pragma unroll 4
-      for (int g = lane; g < nvalid * RW; g += 64) {
-        const int cfg = g / RW;
-        const int rem2 = g - cfg * RW;
-        gdst[cfg * (N * N) + rem2] = tile[cfg * MINV_LANE_TS + rem2];
+          for (int g = lane; g < 64 * N * N / VE; g += 64) dst[g] = src[g];
+          done = true;
+        }
+      }
+      if (!done) {
+#pragma unroll 4
+        for (int g = lane; g < nvalid * RW; g += 64) {
+          const int cfg = g / RW;
+          const int rem2 = g - cfg * RW;
+          gdst[cfg * (N * N) + rem2] = tile[cfg * MINV_LANE_TS + rem2];
+        }
       }
       if constexpr (rows != N) __syncthreads();
     }

@@ -276,3 +276,22 @@ def test_rnea_per_pass_surface(name, prec):
     c1, f1 = rbd.rnea_bpass(g["q"][0], g["fpass_f"][0])                 # numpy, unbatched
     assert isinstance(f1, np.ndarray) and f1.shape == (6, rbd.n)
     assert rel_err_rows(f1[None], g["f_acc"][:1]) < TOL64 and rel_err_rows(c1[None], g["c"][:1]) < TOL64
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_crba_vs_golden(name, prec):
+    """crba (RBDReference.py:1091-1124) against the reference's H, and Minv H = I on the device."""
+    dt, tol = prec
+    torch = _torch()
+    g = load_golden(name); rbd = rbd_for(name)
+    (q,) = dev_tensors(dt, g["q"])
+    H = rbd.crba(q)
+    check("H", H, g["H"], tol)
+    assert torch.equal(H, H.transpose(1, 2))
+    eye = torch.einsum("bij,bjk->bik", rbd.minv(q).double(), H.double())
+    err = (eye - torch.eye(rbd.n, device="cuda:0", dtype=torch.float64)).abs().max().item()
+    assert err < (1e-9 if dt == torch.float64 else 5e-3)
+    rng = np.random.default_rng(9)
+    qb = torch.tensor(rng.uniform(-3, 3, (130, rbd.n)), device="cuda:0", dtype=dt)      # ragged batch
+    from oracle import rbd_oracle as orc
+    check("H ragged", rbd.crba(qb), orc.crba(orc.model_from_robot(make_robot(name)), qb.double().cpu().numpy()), tol)
