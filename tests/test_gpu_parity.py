@@ -295,3 +295,44 @@ def test_crba_vs_golden(name, prec):
     qb = torch.tensor(rng.uniform(-3, 3, (130, rbd.n)), device="cuda:0", dtype=dt)      # ragged batch
     from oracle import rbd_oracle as orc
     check("H ragged", rbd.crba(qb), orc.crba(orc.model_from_robot(make_robot(name)), qb.double().cpu().numpy()), tol)
+
+
+@pytest.mark.parametrize("name", ["iiwa_like", "quadruped_like", "random_prismatic_n6"])
+@pytest.mark.parametrize("grav", [0.0, -3.71, 9.81])
+def test_gravity_argument(name, grav):
+    """GRAVITY is a runtime argument of every entry point (reference default -9.81, :559,:623,:1345)."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    robot = make_robot(name); rbd = rbd_for(name); om = orc.model_from_robot(robot)
+    rng = np.random.default_rng(77)
+    n = rbd.n
+    q = rng.uniform(-np.pi, np.pi, (70, n)); qd = rng.uniform(-1, 1, (70, n)); qdd = rng.uniform(-1, 1, (70, n))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    c_ref, dc_ref = orc.rnea_grad(om, q, qd, qdd, GRAVITY=grav, return_c=True)
+    c, dc = rbd.rnea_grad(tq, tqd, tqdd, GRAVITY=grav, return_c=True)
+    check("dc_du", dc, dc_ref, TOL64)
+    if np.abs(c_ref).max() > 0:
+        check("c", c, c_ref, TOL64)
+    cr, vr, ar, fr = orc.rnea(om, q, qd, qdd, GRAVITY=grav)
+    c2, v, a, f = rbd.rnea(tq, tqd, tqdd, GRAVITY=grav)
+    check("a", a, ar, TOL64); check("f", f, fr, TOL64)
+    if grav == 0.0:      # zero gravity, zero motion => exactly zero torques (SURVEY.md §4 invariant)
+        z = torch.zeros_like(tq)
+        c0, dc0 = rbd.rnea_grad(tq, z, z, GRAVITY=0.0, return_c=True)
+        assert float(c0.abs().max()) == 0.0
+
+
+def test_large_angles_and_nan_propagation():
+    """q far outside [-pi, pi] takes sincosf's slow range reduction; NaN inputs give NaN outputs
+    for that row only."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    robot = make_robot("iiwa_like"); rbd = rbd_for("iiwa_like"); om = orc.model_from_robot(robot)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-1e4, 1e4, (64, 7)); qd = rng.uniform(-1, 1, (64, 7)); qdd = rng.uniform(-1, 1, (64, 7))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    check("dc_du large q", rbd.rnea_grad(tq, tqd, tqdd), orc.rnea_grad(om, q, qd, qdd), 1e-9)
+    check("minv large q", rbd.minv(tq), orc.minv(om, q), 1e-9)
+    sq = tq.float(); sq[3, 2] = float("nan")
+    dc = rbd.rnea_grad(sq, tqd.float(), tqdd.float())
+    assert torch.isnan(dc[3]).any() and torch.isfinite(dc[:3]).all() and torch.isfinite(dc[4:]).all()
