@@ -46,12 +46,21 @@ def header_path(m: PackedModel) -> str:
     return os.path.join(BUILD_DIR, f"model_{m.hash}.h")
 
 
-def _sources_mtime() -> float:
-    t = 0.0
-    for f in os.listdir(CSRC):
-        t = max(t, os.path.getmtime(os.path.join(CSRC, f)))
-    t = max(t, os.path.getmtime(os.path.join(os.path.dirname(HERE), "include", "rbd_hip.h")))
-    return t
+def _sources_digest(m: PackedModel, flags) -> str:
+    """Content hash of everything a library is built from (kernel sources, C-ABI header, generated
+    model header, compiler flags).  Staleness is decided by content, not mtimes: the libraries travel
+    between machines (build container -> GPU box) where timestamps mean nothing."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(os.path.dirname(HERE), "include", "rbd_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(emit_header(m).encode())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
 
 
 TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64",
@@ -76,13 +85,15 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
     out = lib_path(m)
     if tag:                                   # experiment builds live beside the real one
         out = out[:-3] + f".{tag}.so"
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= _sources_mtime():
+    flags = list(HIPCC_FLAGS) + list(extra_flags or [])
+    digest = _sources_digest(m, flags)
+    stamp = out + ".stamp"
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return out
     hdr = header_path(m)
     with open(hdr, "w") as f:
         f.write(emit_header(m))
     src = os.path.join(CSRC, "rbd_kernels.hip")
-    flags = list(HIPCC_FLAGS) + list(extra_flags or [])
 
     def compile_tu(tu):
         obj = os.path.join(BUILD_DIR, f"obj_{m.hash}_{tag}_{tu}.o")
@@ -100,6 +111,8 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
     _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out + ".tmp"],
          f"{m.name} link")
     os.replace(out + ".tmp", out)
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     for o in objs:
         os.remove(o)
     return out
