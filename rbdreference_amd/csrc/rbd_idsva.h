@@ -159,6 +159,13 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
   const int nvalid = rem < CFGS ? (int)rem : CFGS;
   const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
 
+#ifdef RBD_EXP_STAMPS
+#define IDS_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+  unsigned long long stamps[8];
+#else
+#define IDS_STAMP(k) do {} while (0)
+#endif
+  IDS_STAMP(0);
   JTrig<T> tr[N];
   T qv[N], qdv[N], qddv[N];
   auto load_group = [&](auto G) {
@@ -182,7 +189,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     constexpr int last = row0 + rows - 1;
     T* my = tile + lane * GRAD_TS - row0 * GRAD_ROW;   // my[i * 2N + c] (dq), + N (dqd)
     if constexpr (rt == grp_first()) load_group(Rt);
+#ifdef RBD_EXP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    IDS_STAMP(1);
     sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (grp_has(rt, j)) tr[j] = make_trig<j>(qv[j]); });
+    IDS_STAMP(2);
     if constexpr (grp_next(rt) >= 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
 
     // ---- forward: world kinematics of the chain (:1413-1434) ------------------------------------
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
       }
     });
 
+    IDS_STAMP(3);
     // ---- backward: local inertia terms, composites, t-vectors, all pairs of the body -------------
     RInertia<T> IC;
     SymB<T> SC;
@@ -439,6 +452,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     });
 
     // ---- stream this group's rows out ---------------------------------------------------------------
+    IDS_STAMP(4);
     __syncthreads();
     {
       constexpr int RW = rows * GRAD_ROW;
@@ -465,6 +479,13 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
       }
     }
     if constexpr (rows != N) __syncthreads();
+#ifdef RBD_EXP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IDS_STAMP(5);
+    if (lane == 0 && c_out != nullptr) {   // DIAGNOSTIC BUILD ONLY
+      for (int k = 0; k < 5; ++k) c_out[cfg0 * N + k] = (T)(float)(stamps[k + 1] - stamps[k]);
+    }
+#endif
    }
   });
 }

@@ -16,8 +16,8 @@ c = torch.empty((B, 7), dtype=torch.float32, device="cuda"); dc = torch.empty((B
 for _ in range(3):
     f(q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), -9.81, 0, B, c.data_ptr(), dc.data_ptr(), None)
 torch.cuda.synchronize()
-s = c[::32].cpu().numpy()
-names = ["loads", "sincos", "pass1 rnea fwd+bwd", "pass2 sweep", "park LDS+barrier"]
+s = c[::64].cpu().numpy()
+names = ["loads", "sincos", "forward", "backward", "flush (+store drain)"]
 tot = s[:, :5].sum(1)
 print("per-wave ticks (s_memtime, 100 MHz realtime? or shader clock): median / mean")
 for k, nm in enumerate(names):
