@@ -93,33 +93,57 @@ def time_kernel_ms(fn, steps, warmup):
 
 
 def cpu_baseline(robot, seed, budget_s=15.0):
-    """The CPU oracle (numpy restatement of the reference) on a bounded sample of the workload."""
+    """CPU baseline on a bounded sample of the same workload: the C restatement of the oracle
+    (oracle/rbd_oracle.c: the reference's passes, dense 6x6 arithmetic, float64, one configuration
+    at a time per thread, OpenMP over rows on every host core); the numpy oracle's rates are
+    reported beside it."""
     from oracle import rbd_oracle as orc
     om = orc.model_from_robot(robot)
     rng = np.random.default_rng(seed)
+    extra = {}
+    try:
+        from oracle.c_oracle import COracle
+        co = COracle(robot)
+        threads = co.max_threads
+        chunk = 1 << 16
+        q = rng.uniform(-np.pi, np.pi, (chunk, om.n)); qd = rng.uniform(-1, 1, (chunk, om.n)); qdd = rng.uniform(-1, 1, (chunk, om.n))
+        outb = (np.zeros((chunk, om.n)), np.zeros((chunk, om.n, 2 * om.n)))
+        co.rnea_grad(q, qd, qdd, out=outb)                            # warm-up (thread pool, pages)
+        done = 0
+        t0 = time.perf_counter()
+        while True:
+            co.rnea_grad(q, qd, qdd, out=outb)
+            done += chunk
+            el = time.perf_counter() - t0
+            if el > budget_s or done >= (1 << 24):
+                break
+        t1 = time.perf_counter(); co.rnea_grad(q[:8192], qd[:8192], qdd[:8192], threads=1); one = 8192 / (time.perf_counter() - t1)
+        main = {"value": done / el, "unit": "evals/s", "cores": threads, "kind": "port",
+                "sample": f"{done} rows of the same workload (chunks of {chunk}) through oracle/rbd_oracle.c "
+                          f"(float64, dense 6x6 restatement of the reference's passes, OpenMP x{threads}); "
+                          f"1 thread: {one:.0f} evals/s"}
+    except Exception as e:           # no gcc on the box: fall back to the numpy oracle as the baseline
+        main = None
+        extra["c_oracle_error"] = repr(e)
     chunk = 4096
     q = rng.uniform(-np.pi, np.pi, (chunk, om.n)); qd = rng.uniform(-1, 1, (chunk, om.n)); qdd = rng.uniform(-1, 1, (chunk, om.n))
-    orc.rnea_grad(om, q[:64], qd[:64], qdd[:64], return_c=True)   # warm-up
-    done = 0
-    t0 = time.perf_counter()
-    while True:
-        orc.rnea_grad(om, q, qd, qdd, return_c=True)
-        done += chunk
-        el = time.perf_counter() - t0
-        if el > budget_s or done >= (1 << 20):
-            break
-    # the reference's own style: one configuration per call
-    t1 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t1 < 3.0:
-        orc.rnea_grad(om, q[k % chunk], qd[k % chunk], qdd[k % chunk])
-        k += 1
+    orc.rnea_grad(om, q[:64], qd[:64], qdd[:64], return_c=True)
+    t0 = time.perf_counter(); done = 0
+    while time.perf_counter() - t0 < (3.0 if main else budget_s):
+        orc.rnea_grad(om, q, qd, qdd, return_c=True); done += chunk
+    np_rate = done / (time.perf_counter() - t0)
+    t1 = time.perf_counter(); k = 0
+    while time.perf_counter() - t1 < 2.0:       # the reference's own style: one configuration per call
+        orc.rnea_grad(om, q[k % chunk], qd[k % chunk], qdd[k % chunk]); k += 1
     per_call = k / (time.perf_counter() - t1)
-    return {"value": done / el, "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"{done} rows of the same workload in chunks of {chunk} through oracle/rbd_oracle.py "
-                      f"(numpy fp64, batch-vectorised, 1 thread); one-configuration-per-call style "
-                      f"(the reference's own) = {per_call:.0f} evals/s",
-            "host_cpus": os.cpu_count()}
+    if main is None:
+        main = {"value": np_rate, "unit": "evals/s", "cores": 1, "kind": "port",
+                "sample": f"{done} rows through oracle/rbd_oracle.py (numpy fp64, batch-vectorised, 1 thread)"}
+    main["numpy_oracle_batched_evals_per_s_1thread"] = np_rate
+    main["numpy_oracle_one_config_per_call_evals_per_s"] = per_call
+    main["host_cpus"] = os.cpu_count()
+    main.update(extra)
+    return main
 
 
 def main():
