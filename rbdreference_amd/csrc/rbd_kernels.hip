@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
 
 }  // namespace rbdk
 #include "rbd_minv_lane.h"
+#include "rbd_minv_ia8.h"
 #include "rbd_crba.h"
 namespace rbdk {
 #ifdef RBD_NO_MINV_LANE
@@ -897,6 +898,7 @@ constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
 // =============================================================================================
 #include "../../include/rbd_hip.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 // The library is built from several translation units of this one file (rbdreference_amd/build.py
@@ -1075,7 +1077,13 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   hipStream_t s = (hipStream_t)stream;
   T* ws = reinterpret_cast<T*>(workspace);
-  hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
+  // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
+  // otherwise eight lanes per configuration (rbd_minv_ia8.h)
+  if (B >= 64 * 1024 * 4 || std::getenv("RBD_MINV_IA1") != nullptr) {
+    hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
+  } else {
+    hipLaunchKernelGGL(minv_ia8_kernel<T>, dim3((unsigned)((B + 7) / 8)), dim3(64), 0, s, q, (long long)B, ws);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase A launch");
   const size_t lds = sizeof(T) * ((size_t)MINV_CPB * MINV_TS + (size_t)MINV_CPB * N * MINV_WS);
