@@ -89,9 +89,11 @@ def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     robots = [(nm, mk(), 100 + k) for k, (nm, mk) in enumerate(BUILTIN_ROBOTS.items())]
-    # two extra fixtures with generic (dense) joint frames / a prismatic joint mix
+    # extra fixtures with generic (dense) joint frames: a tree, a chain, a prismatic joint mix
     robots.append(("random_tree_n9", random_tree([-1, 0, 1, 1, 3, -1, 5, 5, 7], seed=7,
                                                   name="random_tree_n9"), 201))
+    robots.append(("random_chain_n7", random_tree([-1, 0, 1, 2, 3, 4, 5], seed=21,
+                                                   name="random_chain_n7"), 203))
     robots.append(("random_prismatic_n6", random_tree([-1, 0, 1, 2, 2, 4], seed=11,
                                                        prismatic_every=3,
                                                        name="random_prismatic_n6"), 202))

@@ -36,6 +36,8 @@ def make_robot(name):
         return BUILTIN_ROBOTS[name]()
     if name == "random_tree_n9":
         return random_tree([-1, 0, 1, 1, 3, -1, 5, 5, 7], seed=7, name=name)
+    if name == "random_chain_n7":
+        return random_tree([-1, 0, 1, 2, 3, 4, 5], seed=21, name=name)
     if name == "random_prismatic_n6":
         return random_tree([-1, 0, 1, 2, 2, 4], seed=11, prismatic_every=3, name=name)
     raise KeyError(name)
