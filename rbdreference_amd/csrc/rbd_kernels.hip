@@ -322,6 +322,35 @@ RBD_DEV double from_odd_lane<double>(double x) {
   int hi = __builtin_amdgcn_mov_dpp((int)(u >> 32), 0xF5, 0xF, 0xF, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+// DPP quad_perm [0,0,2,2]: every lane reads the even lane of its pair
+RBD_DEV float from_even_lane(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xA0, 0xF, 0xF, true));
+}
+RBD_DEV double from_even_lane(double x) {
+  unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int lo = __builtin_amdgcn_mov_dpp((int)(u & 0xffffffffu), 0xA0, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_mov_dpp((int)(u >> 32), 0xA0, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// The two lanes of a configuration need the same sin/cos of every joint: for two consecutive bodies of
+// the same joint type the even lane evaluates the first, the odd lane the second (one sincos call in
+// the instruction stream instead of two) and the results are exchanged with DPP.
+template <int G, int J0, class T>
+RBD_DEV void pair_trig(bool isqd, const T (&qv)[N], JTrig<T> (&tr)[N]) {
+  if constexpr (J0 < N) {
+    if constexpr (!grp_has(G, J0)) {
+      pair_trig<G, J0 + 1>(isqd, qv, tr);
+    } else if constexpr (J0 + 1 < N && grp_has(G, J0 + 1) && JTYPE[J0] == JTYPE[J0 + 1]) {
+      const JTrig<T> mine = make_trig<J0>(sel(isqd, qv[J0 + 1], qv[J0]));
+      tr[J0].s = from_even_lane(mine.s); tr[J0].c = from_even_lane(mine.c);
+      tr[J0 + 1].s = from_odd_lane(mine.s); tr[J0 + 1].c = from_odd_lane(mine.c);
+      pair_trig<G, J0 + 2>(isqd, qv, tr);
+    } else {
+      tr[J0] = make_trig<J0>(qv[J0]);
+      pair_trig<G, J0 + 1>(isqd, qv, tr);
+    }
+  }
+}
 
 // Occupancy request (waves per SIMD) for the register allocator.  fp32 needs ~178 VGPRs at n = 7:
 // asking for 3 waves (168) makes the allocator spill ~17 values to scratch, which measured +45 % HBM
@@ -417,7 +446,7 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RBD_STAMP(1);
-  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (grp_has(rt, j)) tr[j] = make_trig<j>(qv[j]); });
+  pair_trig<rt, 0>(isqd, qv, tr);
   if constexpr (grp_next(rt) >= 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
   RBD_STAMP(2);
 
