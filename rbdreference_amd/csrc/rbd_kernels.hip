@@ -4,17 +4,22 @@
 // (rbdreference_amd/build.py).  The path restated here is RBDReference.rnea / rnea_grad / minv,
 // /root/reference/RBDReference.py:559-806, 1127-1368; line cites below are into that file.
 //
-// Work mapping:
-//   rnea        one configuration per lane; outputs transposed through LDS for coalesced stores.
-//   rnea_grad   TWO lanes per configuration: even lane = d/dq columns, odd lane = d/dqd columns.
-//               Both run the same instruction stream (the two recursions differ only in their seed
-//               terms, :1159/:1173 vs :1231/:1243).  The reference's backward passes (:1257-1343)
-//               are replaced by the equivalent forward identity
+// Work mapping; which kernel serves a robot is decided at compile time:
+//   rnea        rnea_kernel: one configuration per lane; outputs leave through LDS tiles as coalesced
+//               (flat 16-byte where the tile is unpadded) stores; big robots park v, a in LDS.
+//   rnea_grad   (a) rnea_grad_idsva_kernel (rbd_idsva.h): ONE lane per configuration, world-frame
+//               composite quantities, every dc_du entry produced once -- long all-revolute chains.
+//               (b) rnea_grad_kernel (below): TWO lanes per configuration (even = d/dq columns, odd =
+//               d/dqd columns, one instruction stream; the recursions :1139-1185 / :1210-1252 differ
+//               only in their seeds).  The reference's backward passes (:1257-1343) are folded into
+//               the forward sweep through
 //                   dc[i, c] = sum_{j in subtree(i) & subtree(c)} Phi[i, j]^T df[c, j],
-//                   Phi[i, j] = X_{j<-i} S_i = dv_dqd[:, i, j]
-//               so no (6, n, NB) df tensor is ever stored: each body contributes 6-term dot
-//               products that are accumulated straight into an LDS image of the output tile, which
-//               is then written to HBM with fully coalesced stores.
+//                   Phi[i, j] = X_{j<-i} S_i = dv_dqd[:, i, j],
+//               accumulated in registers and parked once in the LDS image of the output tile.
+//   minv        minv_lane_kernel (rbd_minv_lane.h): one lane per configuration, fused, for robots with
+//               small root groups; otherwise phase A (minv_ia_kernel / minv_ia8_kernel) + phase B
+//               (minv_cols_kernel, one lane per COLUMN) through a [body][config][12] workspace.
+//   crba, rnea_fpass / rnea_bpass, forward_dynamics(_grad): further rows, same building blocks.
 #include "rbd_spatial.h"
 
 namespace rbdk {
