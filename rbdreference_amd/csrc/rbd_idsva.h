@@ -145,11 +145,18 @@ RBD_DEV void sym_apply(const SymB<T>& S, const T (&x)[6], T (&y)[6]) {
 // rnea_grad, one configuration per lane (64 per block).  Same signature and output layout as
 // rnea_grad_kernel<T, HAS_QDD, false>.
 // ---------------------------------------------------------------------------------------------
-template <class T, bool HAS_QDD>
+// FDG (single-group robots only) = forward_dynamics_grad epilogue (RBDReference.py:1376-1384): when
+// the sweep is over and the registers are free, every lane pulls its finished dc_du row out of the
+// LDS tile, the block's Minv rows ([64][n*n], contiguous in `minv_in`) are staged through the now
+// idle tile with coalesced loads, and [qdd_dq | qdd_dqd] = -Minv dc_du goes back into the tile for
+// the usual flush.  No extra LDS (an earlier version with a separate Minv tile dropped to 4 blocks per
+// CU and ran 2x slower), no dc_du round trip through HBM.
+template <class T, bool HAS_QDD, bool FDG = false>
 __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                                 const T* __restrict__ qdd, T grav, int use_damping,
                                                                 long long B, T* __restrict__ c_out,
-                                                                T* __restrict__ dcdu) {
+                                                                T* __restrict__ dcdu, const T* __restrict__ minv_in = nullptr) {
+  static_assert(!FDG || grad_max_rows() == N, "fused -Minv epilogue: single-group robots only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
@@ -451,6 +458,30 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
       }
     });
 
+    if constexpr (FDG) {
+      T D[GRAD_TILE];
+      sfor<0, GRAD_TILE>([&](auto K_) { constexpr int k = decltype(K_)::value; D[k] = my[k]; });
+      __syncthreads();                                   // every lane has its row in registers
+      {
+        const T* msrc = minv_in + cfg0 * (N * N);
+        for (int g = lane; g < nvalid * N * N; g += CFGS) tile[g] = msrc[g];
+      }
+      __syncthreads();
+      T Mm[N * N];
+      {
+        const T* mrow = tile + (lane < nvalid ? lane : 0) * (N * N);
+        sfor<0, N * N>([&](auto K_) { constexpr int k = decltype(K_)::value; Mm[k] = mrow[k]; });
+      }
+      __syncthreads();                                   // Minv is in registers; the tile can take the outputs
+      sfor<0, N>([&](auto I_) {
+        sfor<0, 2 * N>([&](auto C_) {
+          constexpr int i = decltype(I_)::value, c = decltype(C_)::value;
+          T o = T(0);
+          sfor<0, N>([&](auto K_) { constexpr int k = decltype(K_)::value; o = fma_(-Mm[i * N + k], D[k * GRAD_ROW + c], o); });
+          my[i * GRAD_ROW + c] = o;
+        });
+      });
+    }
     // ---- stream this group's rows out ---------------------------------------------------------------
     IDS_STAMP(4);
     __syncthreads();

@@ -1069,11 +1069,11 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
     if (qdd) {
       auto k = rnea_grad_idsva_kernel<T, true>;
       if ((rc = ensure_lds(k, lds)) != 0) return rc;
-      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du, (const T*)nullptr);
     } else {
       auto k = rnea_grad_idsva_kernel<T, false>;
       if ((rc = ensure_lds(k, lds)) != 0) return rc;
-      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du, (const T*)nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
@@ -1199,7 +1199,18 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
                            stream, u, c, qdd_buf)) != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
-  if constexpr (GRAD_ACC_IN_REGS) {
+  if constexpr (GRAD_USE_IDSVA && grad_max_rows() == N) {
+    const int64_t blocks = (B + 63) / 64;
+    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
+    const size_t lds = sizeof(T) * (size_t)64 * GRAD_TS;
+    auto k = rnea_grad_idsva_kernel<T, true, true>;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)qdd_buf, gravity, 0,
+                       (long long)B, (T*)nullptr, dqdd_du, (const T*)Mi);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad launch");
+    return 0;
+  } else if constexpr (GRAD_ACC_IN_REGS) {
     return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);
   } else {
     T* dc = reinterpret_cast<T*>(w + L.off_dcdu);
