@@ -238,7 +238,7 @@ def main():
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_eval": BYTES_PER_EVAL, "kernel": "rnea_grad_idsva_kernel<float,true>",
+                         "algorithmic_bytes_per_eval": BYTES_PER_EVAL, "kernel": "rnea_grad_idsva_kernel<float,true,false>",
                          "kernel_ms": kern_ms,
                          "note": "kernel is FP32-VALU-bound (SURVEY.md §8d); HBM fraction from algorithmic bytes"},
             "parity_max_rel_err_first_256_rows": parity,
