@@ -69,6 +69,29 @@ int rbd_rnea_fpass_f64(const double* q, const double* qd, const double* qdd, dou
 int rbd_rnea_bpass_f32(const float* q, float* f, int64_t B, float* c, void* stream);
 int rbd_rnea_bpass_f64(const double* q, double* f, int64_t B, double* c, void* stream);
 
+/* Gradient passes (README.md:19).  Layouts as the reference returns them, batch outermost:
+ *   dv, da, df : [B, 6, n, NB]  -- element [b, r, c, i] = d(component r of body i) / d u_c
+ * RBDReference.rnea_grad_fpass_dq(q, qd, v, a, GRAVITY) -> (dv_dq, da_dq, df_dq)     (RBDReference.py:1127-1187)
+ *   v, a [B,6,NB] are the outputs of rnea (a includes the S qdd term, :1353-1358).
+ * RBDReference.rnea_grad_fpass_dqd(q, qd, v) -> (dv_dqd, da_dqd, df_dqd)             (RBDReference.py:1189-1255)
+ * RBDReference.rnea_grad_bpass_dq(q, f, df_dq) -> dc_dq [B,n,n]                      (RBDReference.py:1257-1297)
+ *   f [B,6,NB] is the ACCUMULATED rnea force (:1353,:1362); df_dq is accumulated child -> parent
+ *   IN PLACE as the reference does (:1291-1294).
+ * RBDReference.rnea_grad_bpass_dqd(q, df_dqd, USE_VELOCITY_DAMPING) -> dc_dqd [B,n,n] (RBDReference.py:1299-1343)
+ *   df_dqd accumulated in place (:1331). */
+int rbd_rnea_grad_fpass_dq_f32(const float* q, const float* qd, const float* v, const float* a, float gravity, int64_t B,
+                               float* dv_dq, float* da_dq, float* df_dq, void* stream);
+int rbd_rnea_grad_fpass_dqd_f32(const float* q, const float* qd, const float* v, int64_t B, float* dv_dqd, float* da_dqd,
+                                float* df_dqd, void* stream);
+int rbd_rnea_grad_bpass_dq_f32(const float* q, const float* f, float* df_dq, int64_t B, float* dc_dq, void* stream);
+int rbd_rnea_grad_bpass_dqd_f32(const float* q, float* df_dqd, int use_damping, int64_t B, float* dc_dqd, void* stream);
+int rbd_rnea_grad_fpass_dq_f64(const double* q, const double* qd, const double* v, const double* a, double gravity, int64_t B,
+                               double* dv_dq, double* da_dq, double* df_dq, void* stream);
+int rbd_rnea_grad_fpass_dqd_f64(const double* q, const double* qd, const double* v, int64_t B, double* dv_dqd, double* da_dqd,
+                                double* df_dqd, void* stream);
+int rbd_rnea_grad_bpass_dq_f64(const double* q, const double* f, double* df_dq, int64_t B, double* dc_dq, void* stream);
+int rbd_rnea_grad_bpass_dqd_f64(const double* q, double* df_dqd, int use_damping, int64_t B, double* dc_dqd, void* stream);
+
 /* RBDReference.rnea_grad(q, qd, qdd=None, GRAVITY, USE_VELOCITY_DAMPING)   (RBDReference.py:1345-1368)
  *   dc_du : [B, n, 2n] = [dc_dq | dc_dqd]  (np.hstack, :1367)
  *   c     : [B, n] or NULL -- the bias force the reference computes on the way (:1353) and drops. */
@@ -89,9 +112,28 @@ int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void*
 int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* Minv passes (README.md:19).
+ * RBDReference.minv_bpass(q) -> (Minv, F, U, Dinv)                                   (RBDReference.py:630-735)
+ *   Minv [B,n,n]: row i filled on the columns of subtree(i) only (:700-708), zero elsewhere;
+ *   F [B,n,6,n]; U [B,n,6]; Dinv [B,n] holds D = S^T U, NOT its inverse, exactly as the reference's
+ *   array of that name does (:698).
+ * RBDReference.minv_fpass(q, Minv, F, U, Dinv) -> Minv                               (RBDReference.py:737-783)
+ *   Minv is updated IN PLACE over whole rows (:771), so its strict lower triangle receives the
+ *   same by-products as in the reference; F is rebuilt (:774-781), its incoming contents are not read. */
+int rbd_minv_bpass_f32(const float* q, int64_t B, float* Minv, float* F, float* U, float* Dinv, void* stream);
+int rbd_minv_fpass_f32(const float* q, int64_t B, float* Minv, float* F, const float* U, const float* Dinv, void* stream);
+int rbd_minv_bpass_f64(const double* q, int64_t B, double* Minv, double* F, double* U, double* Dinv, void* stream);
+int rbd_minv_fpass_f64(const double* q, int64_t B, double* Minv, double* F, const double* U, const double* Dinv, void* stream);
+
 /* RBDReference.crba(q)  (fixed-base branch, RBDReference.py:1091-1124): joint-space inertia H [B, n, n]. */
 int rbd_crba_f32(const float* q, int64_t B, float* H, void* stream);
 int rbd_crba_f64(const double* q, int64_t B, double* H, void* stream);
+
+/* RBDReference.aba(q, qd, tau, f_ext=[], GRAVITY)  (fixed-base branch, RBDReference.py:940-1024) -> qdd [B, n].
+ * Articulated-body algorithm; f_ext is not part of the C-ABI (the fixed-base branch never reads it).
+ * Same result as the forward-dynamics entry points below, i.e. Minv (tau - c), to rounding; no workspace. */
+int rbd_aba_f32(const float* q, const float* qd, const float* tau, float gravity, int64_t B, float* qdd, void* stream);
+int rbd_aba_f64(const double* q, const double* qd, const double* tau, double gravity, int64_t B, double* qdd, void* stream);
 
 /* RBDReference.forward_dynamics(q, qd, u)                 (RBDReference.py:1371-1374)
  *   qdd = minv(q) @ (u - rnea(q, qd)[0])        u, qdd : [B, n]

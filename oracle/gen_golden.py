@@ -21,6 +21,10 @@ Fixture contents (S = number of samples, n = DoF):
     Minv_dense, Minv_upper          [S, n, n]   minv(q, True/False)   (:785)
     H                               [S, n, n]   crba(q) witness       (:1029)
     fd_qdd, fd_dq, fd_dqd           forward_dynamics / _grad          (:1371, :1376)
+    aba_qdd                         [S, n]      aba(q, qd, tau=qdd)   (:817, fixed-base branch :940-1024), run
+                                    on a view of the robot whose get_Imat_by_id returns np.matrix: the
+                                    branch's ``np.matmul(temp, v)[0]`` (:984) is only the full bias force
+                                    for that type (with ndarray inertias it degenerates to one scalar).
 """
 import copy
 import os
@@ -47,12 +51,26 @@ def sample_inputs(n, seed, S=N_SAMPLES):
     return q, qd, qdd
 
 
+class MatrixInertiaView:
+    """The same robot with np.matrix inertias, for ``aba`` only (see the module docstring)."""
+
+    def __init__(self, robot):
+        self._robot = robot
+
+    def __getattr__(self, name):
+        return getattr(self._robot, name)
+
+    def get_Imat_by_id(self, i):
+        return np.matrix(self._robot.get_Imat_by_id(i))
+
+
 def run_reference(robot, q, qd, qdd):
     ref = RefRBD(robot)
+    ref_aba = RefRBD(MatrixInertiaView(robot))
     out = {k: [] for k in (
         "fpass_v fpass_a fpass_f c f_acc c_noqdd dq_dv dq_da dq_df dqd_dv dqd_da dqd_df dc_dq "
         "dc_dqd dc_dqd_damped dc_du dc_du_damped dc_du_noqdd mb_Minv mb_F mb_U mb_Dinv "
-        "Minv_dense Minv_upper H fd_qdd fd_dq fd_dqd").split()}
+        "Minv_dense Minv_upper H fd_qdd fd_dq fd_dqd aba_qdd").split()}
     for s in range(q.shape[0]):
         qs, qds, qdds = q[s].copy(), qd[s].copy(), qdd[s].copy()
         v, a, f = ref.rnea_fpass(qs, qds, qdds)
@@ -82,6 +100,7 @@ def run_reference(robot, q, qd, qdd):
         out["fd_qdd"].append(np.asarray(ref.forward_dynamics(qs, qds, u)).copy())
         a1, a2_ = ref.forward_dynamics_grad(qs, qds, u)
         out["fd_dq"].append(np.asarray(a1).copy()); out["fd_dqd"].append(np.asarray(a2_).copy())
+        out["aba_qdd"].append(np.asarray(ref_aba.aba(qs, qds, u)).copy())
     return {k: np.stack(vv) for k, vv in out.items()}
 
 

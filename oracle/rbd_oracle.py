@@ -418,3 +418,53 @@ def forward_dynamics_grad(m: OracleModel, q, qd, u):
     Mi = minv(m, q)
     return (np.einsum("...ij,...jk->...ik", -Mi, dc_du[..., :n]),
             np.einsum("...ij,...jk->...ik", -Mi, dc_du[..., n:]))
+
+
+def aba(m: OracleModel, q, qd, tau, f_ext=None, GRAVITY=-9.81):
+    """RBDReference.py:940-1024 (fixed-base branch of ``aba``) -> qdd.
+
+    The reference writes ``pA[:,ind] = np.matmul(temp, v[:,ind])[0]`` (``:984``): with an ``np.matrix``
+    inertia (what URDFParser hands out) that is the whole 6-vector ``crf(v) I v``; with a plain
+    ndarray inertia the ``[0]`` picks one scalar and the result is no longer the ABA.  The
+    restatement follows the np.matrix reading, which is the one that agrees with
+    ``forward_dynamics`` (probe: 1e-14)."""
+    q, un = _as_batch(q, m.n)
+    qd, _ = _as_batch(qd, m.n)
+    tau, _ = _as_batch(tau, m.n)
+    B, n = q.shape
+    X = Xmats(m, q)
+    v = np.zeros((B, n, 6)); c = np.zeros((B, n, 6)); a = np.zeros((B, n, 6))
+    pA = np.zeros((B, n, 6)); IA = np.broadcast_to(m.I[None], (B, n, 6, 6)).copy()      # :972
+    U = np.zeros((B, n, 6)); d = np.zeros((B, n)); u = np.zeros((B, n)); qdd = np.zeros((B, n))
+    a0 = np.zeros(6); a0[5] = -GRAVITY                                                  # :954-955
+    for i in range(n):
+        p = m.parent[i]
+        vJ = m.S[i][None, :] * qd[:, i:i + 1]
+        if p == -1:
+            v[:, i] = vJ                                                                # :963
+        else:
+            v[:, i] = np.einsum("bij,bj->bi", X[:, i], v[:, p]) + vJ                    # :966-967
+            c[:, i] = _mxS(m.S[i], v[:, i], qd[:, i:i + 1])                             # :968
+        pA[:, i] = _vxIv(v[:, i], m.I[i])                                               # :974-984
+    for i in range(n - 1, -1, -1):
+        p = m.parent[i]
+        S = m.S[i]
+        U[:, i] = np.einsum("bij,j->bi", IA[:, i], S)                                   # :990
+        d[:, i] = U[:, i] @ S                                                           # :991
+        u[:, i] = tau[:, i] - pA[:, i] @ S                                              # :992
+        if p != -1:
+            Ia = IA[:, i] - np.einsum("bi,bj->bij", U[:, i], U[:, i]) / d[:, i, None, None]   # :996-997
+            pa = pA[:, i] + np.einsum("bij,bj->bi", Ia, c[:, i]) + U[:, i] * (u[:, i] / d[:, i])[:, None]  # :999
+            Xi = X[:, i]
+            IA[:, p] += np.einsum("bji,bjk,bkl->bil", Xi, Ia, Xi)                       # :1001-1004
+            pA[:, p] += np.einsum("bji,bj->bi", Xi, pa)                                 # :1006-1007
+    for i in range(n):
+        p = m.parent[i]
+        Xi = X[:, i]
+        if p == -1:
+            a[:, i] = np.einsum("bij,j->bi", Xi, a0) + c[:, i]                          # :1015
+        else:
+            a[:, i] = np.einsum("bij,bj->bi", Xi, a[:, p]) + c[:, i]                    # :1017
+        qdd[:, i] = (u[:, i] - np.einsum("bj,bj->b", U[:, i], a[:, i])) / d[:, i]       # :1020-1021
+        a[:, i] += m.S[i][None, :] * qdd[:, i:i + 1]                                    # :1022
+    return qdd[0] if un else qdd

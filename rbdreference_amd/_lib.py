@@ -25,6 +25,12 @@ EXPORTED_SYMBOLS = [
     "rbd_crba_f32", "rbd_crba_f64",
     "rbd_fd_workspace_bytes", "rbd_forward_dynamics_f32", "rbd_forward_dynamics_f64",
     "rbd_forward_dynamics_grad_f32", "rbd_forward_dynamics_grad_f64",
+    "rbd_rnea_grad_fpass_dq_f32", "rbd_rnea_grad_fpass_dq_f64",
+    "rbd_rnea_grad_fpass_dqd_f32", "rbd_rnea_grad_fpass_dqd_f64",
+    "rbd_rnea_grad_bpass_dq_f32", "rbd_rnea_grad_bpass_dq_f64",
+    "rbd_rnea_grad_bpass_dqd_f32", "rbd_rnea_grad_bpass_dqd_f64",
+    "rbd_aba_f32", "rbd_aba_f64",
+    "rbd_minv_bpass_f32", "rbd_minv_bpass_f64", "rbd_minv_fpass_f32", "rbd_minv_fpass_f64",
 ]
 
 
@@ -75,6 +81,17 @@ def _declare(lib):
         f.restype = c_int
         f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                       c_void_p]
+        for nm, at in (
+                ("rbd_rnea_grad_fpass_dq", [c_void_p] * 4 + [ft, c_int64] + [c_void_p] * 4),
+                ("rbd_rnea_grad_fpass_dqd", [c_void_p] * 3 + [c_int64] + [c_void_p] * 4),
+                ("rbd_rnea_grad_bpass_dq", [c_void_p] * 3 + [c_int64] + [c_void_p] * 2),
+                ("rbd_rnea_grad_bpass_dqd", [c_void_p] * 2 + [c_int, c_int64] + [c_void_p] * 2),
+                ("rbd_aba", [c_void_p] * 3 + [ft, c_int64, c_void_p, c_void_p]),
+                ("rbd_minv_bpass", [c_void_p, c_int64] + [c_void_p] * 5),
+                ("rbd_minv_fpass", [c_void_p, c_int64] + [c_void_p] * 5)):
+            f = getattr(lib, f"{nm}_{sfx}")
+            f.restype = c_int
+            f.argtypes = at
     lib.rbd_minv_workspace_bytes.restype = c_size_t
     lib.rbd_minv_workspace_bytes.argtypes = [c_int64, c_int]
     lib.rbd_fd_workspace_bytes.restype = c_size_t

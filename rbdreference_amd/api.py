@@ -153,6 +153,137 @@ class RBDReference:
             return self._ret(c, unb, is_np), f
         return self._ret(c, unb, is_np), self._ret(fc, unb, is_np)
 
+    # ---- auxiliary (non-[B,n]) operands of the per-pass methods ---------------------------------
+    def _aux(self, x, shape, unb, is_np, dev, dt, name):
+        """Device tensor [B, *shape] for a per-pass operand.  Returns ``(work, origin)``: ``work`` is
+        the contiguous device tensor handed to the kernel, ``origin`` the caller's object (tensor or
+        writable ndarray) that an in-place pass must see updated, or None."""
+        B = shape[0]
+        if isinstance(x, torch.Tensor):
+            if is_np or x.device != dev or x.dtype != dt:
+                raise TypeError(f"{name} must share device and dtype with q")
+            t = x[None] if unb else x
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{name} must have shape {list(shape[1:]) if unb else list(shape)}, got {list(x.shape)}")
+            return (t if t.is_contiguous() else t.contiguous()), x
+        if not is_np:
+            raise TypeError("mixing numpy and torch inputs is not supported")
+        xa = np.asarray(x, dtype=np.float64)
+        xb = xa[None] if unb else xa
+        if xb.shape != tuple(shape):
+            raise ValueError(f"{name} must have shape {list(shape[1:]) if unb else list(shape)}, got {list(xa.shape)}")
+        origin = x if isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.writeable else None
+        return torch.as_tensor(np.ascontiguousarray(xb), device=dev), origin
+
+    @staticmethod
+    def _writeback(work, origin, unb):
+        """Mirror the reference's in-place mutation of an argument (e.g. ``RBDReference.py:1291``)."""
+        if origin is None:
+            return
+        src = work[0] if unb else work
+        if isinstance(origin, torch.Tensor):
+            if origin.data_ptr() != src.data_ptr():
+                origin.copy_(src)
+        else:
+            np.copyto(origin, src.cpu().numpy())
+
+    def rnea_grad_fpass_dq(self, q, qd, v, a, GRAVITY=-9.81):
+        """RBDReference.rnea_grad_fpass_dq (``RBDReference.py:1127-1187``) -> ``(dv_dq, da_dq,
+        df_dq)``, each ``(6, n, NB)`` per configuration; ``v, a`` are rnea's outputs."""
+        (q, qd), unb, is_np, dev, dt = self._prep(q, qd)
+        B, n = q.shape
+        v, _ = self._aux(v, (B, 6, n), unb, is_np, dev, dt, "v")
+        a, _ = self._aux(a, (B, 6, n), unb, is_np, dev, dt, "a")
+        with torch.cuda.device(dev):
+            dv = torch.empty((B, 6, n, n), device=dev, dtype=dt)
+            da = torch.empty_like(dv)
+            df = torch.empty_like(dv)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_grad_fpass_dq", dt)(
+                self._ptr(q), self._ptr(qd), self._ptr(v), self._ptr(a), float(GRAVITY), B,
+                self._ptr(dv), self._ptr(da), self._ptr(df), st))
+        return tuple(self._ret(t, unb, is_np) for t in (dv, da, df))
+
+    def rnea_grad_fpass_dqd(self, q, qd, v):
+        """RBDReference.rnea_grad_fpass_dqd (``RBDReference.py:1189-1255``) -> ``(dv_dqd, da_dqd,
+        df_dqd)``, each ``(6, n, NB)`` per configuration."""
+        (q, qd), unb, is_np, dev, dt = self._prep(q, qd)
+        B, n = q.shape
+        v, _ = self._aux(v, (B, 6, n), unb, is_np, dev, dt, "v")
+        with torch.cuda.device(dev):
+            dv = torch.empty((B, 6, n, n), device=dev, dtype=dt)
+            da = torch.empty_like(dv)
+            df = torch.empty_like(dv)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_grad_fpass_dqd", dt)(
+                self._ptr(q), self._ptr(qd), self._ptr(v), B, self._ptr(dv), self._ptr(da), self._ptr(df), st))
+        return tuple(self._ret(t, unb, is_np) for t in (dv, da, df))
+
+    def rnea_grad_bpass_dq(self, q, f, df_dq):
+        """RBDReference.rnea_grad_bpass_dq (``RBDReference.py:1257-1297``) -> ``dc_dq (n, n)``.  ``f`` is
+        rnea's ACCUMULATED force; ``df_dq`` is accumulated child -> parent IN PLACE like the
+        reference's argument (``:1291-1294``)."""
+        (q,), unb, is_np, dev, dt = self._prep(q)
+        B, n = q.shape
+        f, _ = self._aux(f, (B, 6, n), unb, is_np, dev, dt, "f")
+        df, origin = self._aux(df_dq, (B, 6, n, n), unb, is_np, dev, dt, "df_dq")
+        with torch.cuda.device(dev):
+            dc = torch.empty((B, n, n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_grad_bpass_dq", dt)(
+                self._ptr(q), self._ptr(f), self._ptr(df), B, self._ptr(dc), st))
+        self._writeback(df, origin, unb)
+        return self._ret(dc, unb, is_np)
+
+    def rnea_grad_bpass_dqd(self, q, df_dqd, USE_VELOCITY_DAMPING=False):
+        """RBDReference.rnea_grad_bpass_dqd (``RBDReference.py:1299-1343``) -> ``dc_dqd (n, n)``;
+        ``df_dqd`` accumulated in place (``:1331``)."""
+        (q,), unb, is_np, dev, dt = self._prep(q)
+        B, n = q.shape
+        df, origin = self._aux(df_dqd, (B, 6, n, n), unb, is_np, dev, dt, "df_dqd")
+        with torch.cuda.device(dev):
+            dc = torch.empty((B, n, n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_grad_bpass_dqd", dt)(
+                self._ptr(q), self._ptr(df), int(bool(USE_VELOCITY_DAMPING)), B, self._ptr(dc), st))
+        self._writeback(df, origin, unb)
+        return self._ret(dc, unb, is_np)
+
+    def minv_bpass(self, q):
+        """RBDReference.minv_bpass (``RBDReference.py:630-735``) -> ``(Minv, F, U, Dinv)`` with shapes
+        ``(n, n), (n, 6, n), (n, 6), (n,)`` per configuration; ``Dinv`` holds ``D`` as there (``:698``)."""
+        (q,), unb, is_np, dev, dt = self._prep(q)
+        B, n = q.shape
+        with torch.cuda.device(dev):
+            Minv = torch.empty((B, n, n), device=dev, dtype=dt)
+            F = torch.empty((B, n, 6, n), device=dev, dtype=dt)
+            U = torch.empty((B, n, 6), device=dev, dtype=dt)
+            D = torch.empty((B, n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_minv_bpass", dt)(
+                self._ptr(q), B, self._ptr(Minv), self._ptr(F), self._ptr(U), self._ptr(D), st))
+        return tuple(self._ret(t, unb, is_np) for t in (Minv, F, U, D))
+
+    def minv_fpass(self, q, Minv, F, U, Dinv):
+        """RBDReference.minv_fpass (``RBDReference.py:737-783``) -> ``Minv`` (updated in place, whole
+        rows as at ``:771``: valid upper triangle, by-products below it).  ``F`` is rebuilt in place
+        (``:774-781``); its incoming values are not read."""
+        (q,), unb, is_np, dev, dt = self._prep(q)
+        B, n = q.shape
+        Mw, Mo = self._aux(Minv, (B, n, n), unb, is_np, dev, dt, "Minv")
+        Fw, Fo = self._aux(F, (B, n, 6, n), unb, is_np, dev, dt, "F")
+        Uw, _ = self._aux(U, (B, n, 6), unb, is_np, dev, dt, "U")
+        Dw, _ = self._aux(Dinv, (B, n), unb, is_np, dev, dt, "Dinv")
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_minv_fpass", dt)(
+                self._ptr(q), B, self._ptr(Mw), self._ptr(Fw), self._ptr(Uw), self._ptr(Dw), st))
+        self._writeback(Mw, Mo, unb)
+        self._writeback(Fw, Fo, unb)
+        if isinstance(Mo, torch.Tensor):
+            return Minv
+        return self._ret(Mw, unb, is_np)
+
     def rnea_grad(self, q, qd, qdd=None, GRAVITY=-9.81, USE_VELOCITY_DAMPING=False,
                   return_c: bool = False):
         """RBDReference.rnea_grad (``RBDReference.py:1345-1368``) -> ``dc_du = [dc_dq | dc_dqd]``,
@@ -199,6 +330,18 @@ class RBDReference:
         return self._ret(H, unb, is_np)
 
     # ---- next row of SURVEY.md §8f: forward dynamics on top of the three kernels --------------
+    def aba(self, q, qd, tau, f_ext=[], GRAVITY=-9.81):
+        """RBDReference.aba (fixed-base branch, ``RBDReference.py:940-1024``) -> ``qdd``; ``f_ext`` is
+        accepted and ignored exactly as that branch does."""
+        (q, qd, tau), unb, is_np, dev, dt = self._prep(q, qd, tau)
+        B = q.shape[0]
+        with torch.cuda.device(dev):
+            qdd = torch.empty((B, self.n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_aba", dt)(
+                self._ptr(q), self._ptr(qd), self._ptr(tau), float(GRAVITY), B, self._ptr(qdd), st))
+        return self._ret(qdd, unb, is_np)
+
     def _fd(self, q, qd, u, GRAVITY, want_grad):
         (q, qd, u), unb, is_np, dev, dt = self._prep(q, qd, u)
         B = q.shape[0]

@@ -64,7 +64,7 @@ def _sources_digest(m: PackedModel, flags) -> str:
 
 
 TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64",
-                     "FD_F32", "FD_F64"]
+                     "FD_F32", "FD_F64", "PASS_F32", "PASS_F64"]
 _HIPCC_SLOTS = threading.BoundedSemaphore(max(1, (os.cpu_count() or 2)))
 
 
@@ -79,7 +79,7 @@ def _run(cmd, what):
 def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
                 extra_flags: Optional[list] = None, tag: str = "") -> str:
     """Compile the library for packed model `m` (no-op when an up-to-date one exists).  The single
-    source file is compiled as seven translation units in parallel (-DRBD_TU_*) and linked."""
+    source file is compiled as several translation units in parallel (-DRBD_TU_*) and linked."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(BUILD_DIR, exist_ok=True)
     out = lib_path(m)
@@ -97,7 +97,7 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
 
     def compile_tu(tu):
         obj = os.path.join(BUILD_DIR, f"obj_{m.hash}_{tag}_{tu}.o")
-        cmd = [hipcc_path(), *[f for f in flags if f != "-shared"], f"-DRBD_TU_{tu}=1", "-include", hdr,
+        cmd = [hipcc_path(), *[f for f in flags if f != "-shared"], "-DRBD_TU_SPLIT=1", f"-DRBD_TU_{tu}=1", "-include", hdr,
                "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -917,6 +917,10 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
 #include "rbd_minv_lane.h"
 #include "rbd_minv_ia8.h"
 #include "rbd_crba.h"
+#include "rbd_aba.h"
+#if defined(RBD_TU_PASS_F32) || defined(RBD_TU_PASS_F64) || !defined(RBD_TU_SPLIT)
+#include "rbd_passes.h"
+#endif
 namespace rbdk {
 #ifdef RBD_NO_MINV_LANE
 constexpr bool MINV_USE_LANE = false;
@@ -937,10 +941,9 @@ constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
 
 // The library is built from several translation units of this one file (rbdreference_amd/build.py
 // compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
-// _MINV_F32, _MINV_F64, _FD_F32, _FD_F64; no RBD_TU_* macro at all = everything in one unit.
-#if !defined(RBD_TU_COMMON) && !defined(RBD_TU_RNEA_F32) && !defined(RBD_TU_RNEA_F64) && \
-    !defined(RBD_TU_GRAD_F32) && !defined(RBD_TU_GRAD_F64) && !defined(RBD_TU_MINV_F32) && \
-    !defined(RBD_TU_MINV_F64) && !defined(RBD_TU_FD_F32) && !defined(RBD_TU_FD_F64)
+// _MINV_F32, _MINV_F64, _FD_F32, _FD_F64, _PASS_F32, _PASS_F64 (each together with -DRBD_TU_SPLIT);
+// without RBD_TU_SPLIT everything is compiled in one unit.
+#if !defined(RBD_TU_SPLIT)
 #define RBD_TU_COMMON 1
 #define RBD_TU_RNEA_F32 1
 #define RBD_TU_RNEA_F64 1
@@ -950,6 +953,8 @@ constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
 #define RBD_TU_MINV_F64 1
 #define RBD_TU_FD_F32 1
 #define RBD_TU_FD_F64 1
+#define RBD_TU_PASS_F32 1
+#define RBD_TU_PASS_F64 1
 #endif
 
 // thread-local message buffer behind rbd_last_error(); one instance, owned by the COMMON unit
@@ -1223,6 +1228,88 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     return 0;
   }
 }
+
+#if defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+template <class T>
+int aba_launch(const T* q, const T* qd, const T* tau, T gravity, int64_t B, T* qdd, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_aba: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !tau || !qdd) return fail(RBD_ERR_ARG, "rbd_aba: q, qd, tau and qdd must be non-null");
+  constexpr int lanes = ABA_PARK ? aba_lanes<T>() : 64;
+  const int64_t blocks = (B + lanes - 1) / lanes;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_aba: B too large");
+  constexpr size_t lds = aba_lds_bytes<T>();
+  if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_aba: per-body state does not fit LDS for this robot size");
+  if (int rc = ensure_lds(aba_kernel<T>, lds)) return rc;
+  hipLaunchKernelGGL(aba_kernel<T>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, tau, gravity,
+                     (long long)B, qdd);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_aba launch");
+  return 0;
+}
+#endif
+
+#if defined(RBD_TU_PASS_F32) || defined(RBD_TU_PASS_F64)
+// ---- per-pass entry points (rbd_passes.h) ------------------------------------------------------------
+int pass_blocks(int64_t B, const char* who, unsigned* blocks) {
+  if (B < 0) { std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: B < 0", who); return RBD_ERR_ARG; }
+  const int64_t nb = (B + 63) / 64;
+  if (nb > 0x7fffffffLL) { std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: B too large", who); return RBD_ERR_ARG; }
+  *blocks = (unsigned)nb;
+  return 0;
+}
+int pass_done(const char* who) {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, who);
+}
+template <class T, bool DQ>
+int grad_fpass_launch(const T* q, const T* qd, const T* v, const T* a, T gravity, int64_t B, T* dv, T* da, T* df, void* stream) {
+  const char* who = DQ ? "rbd_rnea_grad_fpass_dq" : "rbd_rnea_grad_fpass_dqd";
+  unsigned blocks;
+  if (int rc = pass_blocks(B, who, &blocks)) return rc;
+  if (B == 0) return 0;
+  if (!q || !qd || !v || (DQ && !a) || !dv || !da || !df) {
+    std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: null pointer argument", who);
+    return RBD_ERR_ARG;
+  }
+  hipLaunchKernelGGL((rbdk::grad_fpass_kernel<T, DQ>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, q, qd, v, a, gravity,
+                     (long long)B, dv, da, df);
+  return pass_done(who);
+}
+template <class T, bool DQ>
+int grad_bpass_launch(const T* q, const T* f, T* df, int use_damping, int64_t B, T* dc, void* stream) {
+  const char* who = DQ ? "rbd_rnea_grad_bpass_dq" : "rbd_rnea_grad_bpass_dqd";
+  unsigned blocks;
+  if (int rc = pass_blocks(B, who, &blocks)) return rc;
+  if (B == 0) return 0;
+  if (!q || (DQ && !f) || !df || !dc) {
+    std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: null pointer argument", who);
+    return RBD_ERR_ARG;
+  }
+  hipLaunchKernelGGL((rbdk::grad_bpass_kernel<T, DQ>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, q, f, df, use_damping,
+                     (long long)B, dc);
+  return pass_done(who);
+}
+template <class T>
+int minv_bpass_launch(const T* q, int64_t B, T* Minv, T* F, T* U, T* D, void* stream) {
+  unsigned blocks;
+  if (int rc = pass_blocks(B, "rbd_minv_bpass", &blocks)) return rc;
+  if (B == 0) return 0;
+  if (!q || !Minv || !F || !U || !D) return fail(RBD_ERR_ARG, "rbd_minv_bpass: null pointer argument");
+  hipLaunchKernelGGL(rbdk::minv_bpass_kernel<T>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, Minv, F, U, D);
+  return pass_done("rbd_minv_bpass");
+}
+template <class T>
+int minv_fpass_launch(const T* q, int64_t B, T* Minv, T* F, const T* U, const T* D, void* stream) {
+  unsigned blocks;
+  if (int rc = pass_blocks(B, "rbd_minv_fpass", &blocks)) return rc;
+  if (B == 0) return 0;
+  if (!q || !Minv || !F || !U || !D) return fail(RBD_ERR_ARG, "rbd_minv_fpass: null pointer argument");
+  hipLaunchKernelGGL(rbdk::minv_fpass_kernel<T>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, Minv, F, U, D);
+  return pass_done("rbd_minv_fpass");
+}
+#endif
 }  // namespace
 
 extern "C" {
@@ -1312,6 +1399,9 @@ int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void*
 }
 #endif
 #ifdef RBD_TU_FD_F32
+int rbd_aba_f32(const float* q, const float* qd, const float* tau, float gravity, int64_t B, float* qdd, void* stream) {
+  return aba_launch<float>(q, qd, tau, gravity, B, qdd, stream);
+}
 int rbd_forward_dynamics_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
                              float* qdd, void* workspace, size_t workspace_bytes, void* stream) {
   return fd_launch<float>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
@@ -1322,6 +1412,9 @@ int rbd_forward_dynamics_grad_f32(const float* q, const float* qd, const float* 
 }
 #endif
 #ifdef RBD_TU_FD_F64
+int rbd_aba_f64(const double* q, const double* qd, const double* tau, double gravity, int64_t B, double* qdd, void* stream) {
+  return aba_launch<double>(q, qd, tau, gravity, B, qdd, stream);
+}
 int rbd_forward_dynamics_f64(const double* q, const double* qd, const double* u, double gravity, int64_t B,
                              double* qdd, void* workspace, size_t workspace_bytes, void* stream) {
   return fd_launch<double>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
@@ -1335,6 +1428,51 @@ int rbd_forward_dynamics_grad_f64(const double* q, const double* qd, const doubl
 int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
                  size_t workspace_bytes, void* stream) {
   return minv_launch<double>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+}
+#endif
+
+#ifdef RBD_TU_PASS_F32
+int rbd_rnea_grad_fpass_dq_f32(const float* q, const float* qd, const float* v, const float* a, float gravity, int64_t B,
+                               float* dv_dq, float* da_dq, float* df_dq, void* stream) {
+  return grad_fpass_launch<float, true>(q, qd, v, a, gravity, B, dv_dq, da_dq, df_dq, stream);
+}
+int rbd_rnea_grad_fpass_dqd_f32(const float* q, const float* qd, const float* v, int64_t B, float* dv_dqd, float* da_dqd,
+                                float* df_dqd, void* stream) {
+  return grad_fpass_launch<float, false>(q, qd, v, nullptr, float(0), B, dv_dqd, da_dqd, df_dqd, stream);
+}
+int rbd_rnea_grad_bpass_dq_f32(const float* q, const float* f, float* df_dq, int64_t B, float* dc_dq, void* stream) {
+  return grad_bpass_launch<float, true>(q, f, df_dq, 0, B, dc_dq, stream);
+}
+int rbd_rnea_grad_bpass_dqd_f32(const float* q, float* df_dqd, int use_damping, int64_t B, float* dc_dqd, void* stream) {
+  return grad_bpass_launch<float, false>(q, nullptr, df_dqd, use_damping, B, dc_dqd, stream);
+}
+int rbd_minv_bpass_f32(const float* q, int64_t B, float* Minv, float* F, float* U, float* Dinv, void* stream) {
+  return minv_bpass_launch<float>(q, B, Minv, F, U, Dinv, stream);
+}
+int rbd_minv_fpass_f32(const float* q, int64_t B, float* Minv, float* F, const float* U, const float* Dinv, void* stream) {
+  return minv_fpass_launch<float>(q, B, Minv, F, U, Dinv, stream);
+}
+#endif
+#ifdef RBD_TU_PASS_F64
+int rbd_rnea_grad_fpass_dq_f64(const double* q, const double* qd, const double* v, const double* a, double gravity, int64_t B,
+                               double* dv_dq, double* da_dq, double* df_dq, void* stream) {
+  return grad_fpass_launch<double, true>(q, qd, v, a, gravity, B, dv_dq, da_dq, df_dq, stream);
+}
+int rbd_rnea_grad_fpass_dqd_f64(const double* q, const double* qd, const double* v, int64_t B, double* dv_dqd, double* da_dqd,
+                                double* df_dqd, void* stream) {
+  return grad_fpass_launch<double, false>(q, qd, v, nullptr, double(0), B, dv_dqd, da_dqd, df_dqd, stream);
+}
+int rbd_rnea_grad_bpass_dq_f64(const double* q, const double* f, double* df_dq, int64_t B, double* dc_dq, void* stream) {
+  return grad_bpass_launch<double, true>(q, f, df_dq, 0, B, dc_dq, stream);
+}
+int rbd_rnea_grad_bpass_dqd_f64(const double* q, double* df_dqd, int use_damping, int64_t B, double* dc_dqd, void* stream) {
+  return grad_bpass_launch<double, false>(q, nullptr, df_dqd, use_damping, B, dc_dqd, stream);
+}
+int rbd_minv_bpass_f64(const double* q, int64_t B, double* Minv, double* F, double* U, double* Dinv, void* stream) {
+  return minv_bpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
+}
+int rbd_minv_fpass_f64(const double* q, int64_t B, double* Minv, double* F, const double* U, const double* Dinv, void* stream) {
+  return minv_fpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
 }
 #endif
 

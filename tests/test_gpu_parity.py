@@ -336,3 +336,121 @@ def test_large_angles_and_nan_propagation():
     sq = tq.float(); sq[3, 2] = float("nan")
     dc = rbd.rnea_grad(sq, tqd.float(), tqdd.float())
     assert torch.isnan(dc[3]).any() and torch.isfinite(dc[:3]).all() and torch.isfinite(dc[4:]).all()
+
+
+# ---- per-pass gradient / Minv surface (README.md:19 of the reference) -----------------------------------
+@pytest.mark.parametrize("name", all_golden_names())
+def test_rnea_grad_passes_vs_golden(name, prec):
+    """rnea_grad_fpass_dq/dqd and rnea_grad_bpass_dq/dqd fed exactly as RBDReference.rnea_grad feeds
+    them (RBDReference.py:1353-1365), against the reference's own per-pass outputs."""
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    q, qd, v, a, f = dev_tensors(dt, g["q"], g["qd"], g["fpass_v"], g["fpass_a"], g["f_acc"])
+    dv, da, df = rbd.rnea_grad_fpass_dq(q, qd, v, a)
+    check("dv_dq", dv, g["dq_dv"], tol); check("da_dq", da, g["dq_da"], tol); check("df_dq", df, g["dq_df"], tol)
+    dv2, da2, df2 = rbd.rnea_grad_fpass_dqd(q, qd, v)
+    check("dv_dqd", dv2, g["dqd_dv"], tol); check("da_dqd", da2, g["dqd_da"], tol)
+    check("df_dqd", df2, g["dqd_df"], tol)
+    # backward passes on the reference's df (the kernels' own df differs by rounding only)
+    (gdf, gdf2) = dev_tensors(dt, g["dq_df"], g["dqd_df"])
+    n = rbd.n
+    check("dc_dq", rbd.rnea_grad_bpass_dq(q, f, gdf), g["dc_dq"], tol)
+    check("dc_dqd", rbd.rnea_grad_bpass_dqd(q, gdf2.clone()), g["dc_dqd"], tol)
+    check("dc_dqd damped", rbd.rnea_grad_bpass_dqd(q, gdf2.clone(), USE_VELOCITY_DAMPING=True),
+          g["dc_dqd_damped"], tol)
+    # chained: our fpass -> our bpass reproduces rnea_grad's halves
+    check("dc_dq (chained)", rbd.rnea_grad_bpass_dq(q, f, df), g["dc_du"][:, :, :n], tol)
+    check("dc_dqd (chained)", rbd.rnea_grad_bpass_dqd(q, df2), g["dc_du"][:, :, n:], tol)
+
+
+@pytest.mark.parametrize("name", ["iiwa_like", "random_tree_n9", "random_prismatic_n6", "atlas_like"])
+def test_rnea_grad_bpass_mutates_df_like_the_reference(name):
+    """The backward passes accumulate df child -> parent in place (RBDReference.py:1291-1294, :1331);
+    checked against the oracle on DENSE random df (the passes accept any input)."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    robot = make_robot(name); rbd = rbd_for(name); om = orc.model_from_robot(robot)
+    n = rbd.n; B = 37
+    rng = np.random.default_rng(77)
+    q = rng.uniform(-np.pi, np.pi, (B, n)); f = rng.normal(size=(B, 6, n))
+    df = rng.normal(size=(B, 6, n, n))
+    df_ref = df.copy(); dc_ref = orc.rnea_grad_bpass_dq(om, q, f, df_ref)
+    tq, tf, tdf = dev_tensors(torch.float64, q, f, df)
+    dc = rbd.rnea_grad_bpass_dq(tq, tf, tdf)
+    check("dc_dq", dc, dc_ref, TOL64); check("df_dq after", tdf, df_ref, TOL64)
+    df2_ref = df.copy(); dc2_ref = orc.rnea_grad_bpass_dqd(om, q, df2_ref, True)
+    (tdf2,) = dev_tensors(torch.float64, df)
+    check("dc_dqd", rbd.rnea_grad_bpass_dqd(tq, tdf2, True), dc2_ref, TOL64)
+    check("df_dqd after", tdf2, df2_ref, TOL64)
+    # numpy in -> the caller's ndarray is updated too, unbatched shapes like the reference's
+    dfn = df[0].copy()
+    dcn = rbd.rnea_grad_bpass_dq(q[0], f[0], dfn)
+    assert dcn.shape == (n, n) and np.abs(dfn - df_ref[0]).max() <= 1e-9 * np.abs(df_ref[0]).max()
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_minv_passes_vs_golden(name, prec):
+    """minv_bpass -> (Minv, F, U, Dinv) and minv_fpass against the reference's per-pass outputs
+    (RBDReference.py:630-783), including the by-products minv_fpass leaves below the diagonal."""
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    tol_m = tol * (10 if dt == _torch().float32 and rbd.n >= 30 else 1)
+    (q,) = dev_tensors(dt, g["q"])
+    Mb, F, U, D = rbd.minv_bpass(q)
+    check("minv_bpass Minv", Mb, g["mb_Minv"], tol_m); check("minv_bpass F", F, g["mb_F"], tol_m)
+    check("minv_bpass U", U, g["mb_U"], tol_m); check("minv_bpass Dinv (= D)", D, g["mb_Dinv"], tol_m)
+    M = rbd.minv_fpass(q, Mb, F, U, D)
+    assert M is Mb                                                  # updated in place, like the reference
+    check("minv_fpass Minv (whole matrix, junk included)", M, g["Minv_upper"], tol_m)
+    # the reference's own bpass outputs as input
+    gM, gF, gU, gD = dev_tensors(dt, g["mb_Minv"], g["mb_F"], g["mb_U"], g["mb_Dinv"])
+    check("minv_fpass on golden inputs", rbd.minv_fpass(q, gM, gF, gU, gD), g["Minv_upper"], tol_m)
+
+
+def test_per_pass_shapes_unbatched_numpy():
+    """(n,) numpy inputs give the reference's unbatched shapes (RBDReference.py:1132-1134, :656-660)."""
+    g = load_golden("iiwa_like"); rbd = rbd_for("iiwa_like"); n = rbd.n
+    q, qd = g["q"][0], g["qd"][0]
+    dv, da, df = rbd.rnea_grad_fpass_dq(q, qd, g["fpass_v"][0], g["fpass_a"][0])
+    assert dv.shape == da.shape == df.shape == (6, n, n) and isinstance(df, np.ndarray)
+    assert np.abs(df - g["dq_df"][0]).max() <= 1e-11 * np.abs(g["dq_df"][0]).max()
+    Mb, F, U, D = rbd.minv_bpass(q)
+    assert Mb.shape == (n, n) and F.shape == (n, 6, n) and U.shape == (n, 6) and D.shape == (n,)
+    M = rbd.minv_fpass(q, Mb, F, U, D)
+    assert np.abs(M - g["Minv_upper"][0]).max() <= 1e-11 * np.abs(g["Minv_upper"][0]).max()
+    with pytest.raises(ValueError):
+        rbd.rnea_grad_fpass_dqd(q, qd, np.zeros((6, n + 1)))
+    with pytest.raises(ValueError):
+        rbd.minv_fpass(q, Mb, F, U[:, :5], D)
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_aba_vs_golden(name, prec):
+    """aba (RBDReference.py:940-1024) against the reference's aba and forward_dynamics outputs."""
+    dt, tol = prec
+    g = load_golden(name); rbd = rbd_for(name)
+    tol_a = 5e-4 if dt == _torch().float32 else 1e-9     # conditioned by cond(H), as forward_dynamics
+    q, qd, tau = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    qdd = rbd.aba(q, qd, tau)
+    check("aba_qdd", qdd, g["aba_qdd"], tol_a); check("aba vs forward_dynamics", qdd, g["fd_qdd"], tol_a)
+    assert rbd.aba(q[0], qd[0], tau[0]).shape == (rbd.n,)
+    assert rbd.aba(g["q"][0], g["qd"][0], g["qdd"][0], f_ext=[]).shape == (rbd.n,)
+
+
+@pytest.mark.parametrize("name,B", [("iiwa_like", 100003), ("atlas_like", 16384), ("quadruped_like", 65536)])
+def test_aba_round_trip_full_size(name, B):
+    """rnea(q, qd, aba(q, qd, tau)) == tau at BASELINE sizes, ragged last block included (fp64)."""
+    torch = _torch()
+    rbd = rbd_for(name); n = rbd.n
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    q = (torch.rand((B, n), device="cuda:0", dtype=torch.float64, generator=gen) * 2 - 1) * np.pi
+    qd = torch.rand((B, n), device="cuda:0", dtype=torch.float64, generator=gen) * 2 - 1
+    tau = torch.rand((B, n), device="cuda:0", dtype=torch.float64, generator=gen) * 2 - 1
+    for grav in (-9.81, 0.0):
+        qdd = rbd.aba(q, qd, tau, GRAVITY=grav)
+        c, _, _, _ = rbd.rnea(q, qd, qdd, GRAVITY=grav, outputs="c")
+        scale = max(1.0, float(qdd.abs().max()))
+        assert float((c - tau).abs().max()) <= 1e-9 * scale
+    q32, qd32, tau32 = q.float(), qd.float(), tau.float()
+    e = rel_err_rows(rbd.aba(q32, qd32, tau32).double().cpu().numpy(), rbd.aba(q, qd, tau).cpu().numpy())
+    assert e <= 2e-3, e       # fp32 forward dynamics is conditioned by cond(H); see test_forward_dynamics_*

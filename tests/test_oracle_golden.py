@@ -109,6 +109,20 @@ def test_crba_witness_and_forward_dynamics(golden_case):
     _chk("fd_dq", a, g["fd_dq"], 1e-10); _chk("fd_dqd", b, g["fd_dqd"], 1e-10)
 
 
+def test_aba(golden_case):
+    """aba (RBDReference.py:940-1024) against the reference's own aba output and its forward_dynamics."""
+    name, robot, g = golden_case
+    m = orc.model_from_robot(robot)
+    qdd = orc.aba(m, g["q"], g["qd"], g["qdd"])
+    _chk("aba_qdd", qdd, g["aba_qdd"], 1e-10)
+    _chk("aba vs fd", qdd, g["fd_qdd"], 1e-9)
+    assert orc.aba(m, g["q"][0], g["qd"][0], g["qdd"][0]).shape == (m.n,)
+    for grav in (0.0, 3.7):
+        a = orc.aba(m, g["q"], g["qd"], g["qdd"], GRAVITY=grav)
+        c = orc.rnea(m, g["q"], g["qd"], a, GRAVITY=grav)[0]       # rnea(aba(tau)) == tau
+        assert np.max(np.abs(c - g["qdd"])) < 1e-9 * max(1.0, np.max(np.abs(a)))
+
+
 @pytest.mark.parametrize("name", ["iiwa_like", "quadruped_like", "atlas_like", "random_tree_n9"])
 def test_invariants_without_reference(name):
     """Maths-only checks (no golden file): finite-difference gradients, Minv H = I, zero gravity."""
