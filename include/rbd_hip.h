@@ -140,9 +140,11 @@ int rbd_aba_f64(const double* q, const double* qd, const double* tau, double gra
  * RBDReference.forward_dynamics_grad(q, qd, u)            (RBDReference.py:1376-1384)
  *   dqdd_du : [B, n, 2n] = [qdd_dq | qdd_dqd] = -minv(q) @ rnea_grad(q, qd, qdd)  (the reference
  *   returns the two halves as a tuple); qdd (nullable) also receives the forward dynamics itself.
- *   Three / four launches on `stream`: rnea (bias force), minv phases A and B with the
- *   Minv (u - c) product fused into phase B, rnea_grad with the -Minv product fused into its epilogue.
- *   workspace: device scratch of at least rbd_fd_workspace_bytes(B, sizeof(T)) bytes, 16-byte aligned. */
+ *   forward_dynamics is one launch (the articulated-body sweeps of rbd_aba give Minv (u - c) without
+ *   forming either factor; its workspace arguments are accepted and unused).  forward_dynamics_grad
+ *   is three / four launches on `stream`: rnea (bias force), minv with the Minv (u - c) product
+ *   fused in, rnea_grad with the -Minv product fused into its epilogue; it needs a device scratch of
+ *   at least rbd_fd_workspace_bytes(B, sizeof(T)) bytes, 16-byte aligned. */
 size_t rbd_fd_workspace_bytes(int64_t B, int elem_size);
 int rbd_forward_dynamics_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
                              float* qdd, void* workspace, size_t workspace_bytes, void* stream);

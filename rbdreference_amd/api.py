@@ -348,22 +348,22 @@ class RBDReference:
         esz = 4 if dt == torch.float32 else 8
         with torch.cuda.device(dev):
             qdd = torch.empty((B, self.n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if not want_grad:        # one articulated-body launch, no scratch
+                self._lib.check(self._fn("rbd_forward_dynamics", dt)(
+                    self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), None, 0, st))
+                return qdd, None, unb, is_np
             wsb = int(self._lib.lib.rbd_fd_workspace_bytes(B, esz))
             ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
-            st = torch.cuda.current_stream(dev).cuda_stream
-            if want_grad:
-                d = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
-                self._lib.check(self._fn("rbd_forward_dynamics_grad", dt)(
-                    self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
-                    self._ptr(d), ws.data_ptr(), wsb, st))
-                return qdd, d, unb, is_np
-            self._lib.check(self._fn("rbd_forward_dynamics", dt)(
+            d = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
+            self._lib.check(self._fn("rbd_forward_dynamics_grad", dt)(
                 self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
-                ws.data_ptr(), wsb, st))
-            return qdd, None, unb, is_np
+                self._ptr(d), ws.data_ptr(), wsb, st))
+            return qdd, d, unb, is_np
 
     def forward_dynamics(self, q, qd, u, GRAVITY=-9.81):
-        """RBDReference.forward_dynamics (``RBDReference.py:1371-1374``): ``minv(q) @ (u - c(q, qd))``."""
+        """RBDReference.forward_dynamics (``RBDReference.py:1371-1374``): ``minv(q) @ (u - c(q, qd))``,
+        evaluated by the articulated-body sweeps (same value to rounding, neither factor is formed)."""
         qdd, _, unb, is_np = self._fd(q, qd, u, GRAVITY, False)
         return self._ret(qdd, unb, is_np)
 

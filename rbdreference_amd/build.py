@@ -95,15 +95,26 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
         f.write(emit_header(m))
     src = os.path.join(CSRC, "rbd_kernels.hip")
 
+    cache_dir = os.path.join(BUILD_DIR, "objcache")
+    os.makedirs(cache_dir, exist_ok=True)
+
     def compile_tu(tu):
-        obj = os.path.join(BUILD_DIR, f"obj_{m.hash}_{tag}_{tu}.o")
-        cmd = [hipcc_path(), *[f for f in flags if f != "-shared"], "-DRBD_TU_SPLIT=1", f"-DRBD_TU_{tu}=1", "-include", hdr,
-               "-c", src, "-o", obj]
+        # Objects are cached by the hash of the PREPROCESSED unit: an edit to one header only
+        # recompiles the units that include it (the optimiser, not the front end, is the cost).
+        import hashlib
+        base = [hipcc_path(), *[f for f in flags if f != "-shared"], "-DRBD_TU_SPLIT=1", f"-DRBD_TU_{tu}=1", "-include", hdr]
+        pre = _run([*base, "-E", "-P", src, "-o", "-"], f"{m.name} {tu} (preprocess)")
+        key = hashlib.sha256((pre.stdout + "\0" + " ".join(flags)).encode()).hexdigest()[:32]
+        obj = os.path.join(cache_dir, f"{key}.o")
+        if os.path.exists(obj) and not force:
+            return obj
+        cmd = [*base, "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = _run(cmd, f"{m.name} {tu}")
         if verbose and r.stderr:
             print(r.stderr, file=sys.stderr)
+        os.replace(obj + f".{os.getpid()}.tmp", obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(TRANSLATION_UNITS)) as ex:
@@ -113,8 +124,6 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
     os.replace(out + ".tmp", out)
     with open(stamp, "w") as f:
         f.write(digest + "\n")
-    for o in objs:
-        os.remove(o)
     return out
 
 
