@@ -7,9 +7,11 @@
 from .robot import (BUILTIN_ROBOTS, Link, Robot, atlas_like, builtin_robot, iiwa_like,
                     quadruped_like, random_tree)
 from .packer import PackedModel, pack_robot
+from .urdf import load_urdf, loads_urdf, to_urdf
 
 __all__ = ["RBDReference", "Robot", "Link", "iiwa_like", "quadruped_like", "atlas_like",
-           "random_tree", "builtin_robot", "BUILTIN_ROBOTS", "pack_robot", "PackedModel"]
+           "random_tree", "builtin_robot", "BUILTIN_ROBOTS", "pack_robot", "PackedModel",
+           "load_urdf", "loads_urdf", "to_urdf"]
 
 
 def __getattr__(name):

@@ -360,11 +360,14 @@ RBD_DEV void pair_trig(bool isqd, const T (&qv)[N], JTrig<T> (&tr)[N]) {
 // Occupancy request (waves per SIMD) for the register allocator.  fp32 needs ~178 VGPRs at n = 7:
 // asking for 3 waves (168) makes the allocator spill ~17 values to scratch, which measured +45 % HBM
 // traffic (PMC) for no sustained speed-up; 2 waves run spill-free.
+// Robots whose LDS tile leaves room for one block per CU only (Atlas: 139 KB) get the whole register
+// file: asking for 2 waves there bought nothing and spilled 140 values.
 template <class T>
 constexpr int grad_min_waves() {
 #ifdef GRAD_MIN_WAVES
   return GRAD_MIN_WAVES;
 #else
+  if ((long long)grad_cfgs<T>() * GRAD_TS * (long long)sizeof(T) > 80 * 1024) return 1;
   return sizeof(T) == 4 ? 2 : 1;
 #endif
 }

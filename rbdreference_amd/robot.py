@@ -99,6 +99,8 @@ class Link:
     inertia: Sequence[float] = (0.01, 0.01, 0.01, 0.0, 0.0, 0.0)  # ixx iyy izz ixy ixz iyz @ com
     damping: float = 0.0
     jtype: str = "revolute"           # or "prismatic"
+    rot: object = None                # optional 3x3 E (child-frame coords of parent-frame vectors);
+                                      # overrides rpy (used by the URDF loader for arbitrary frames)
 
 
 class Robot:
@@ -128,7 +130,8 @@ class Robot:
             else:
                 raise ValueError(f"unsupported joint type {l.jtype!r}")
             self._S.append(S)
-            Xt = plux(_rpy_E(l.rpy), l.xyz)
+            E = _rpy_E(l.rpy) if l.rot is None else _snap(np.asarray(l.rot, dtype=np.float64).reshape(3, 3))
+            Xt = plux(E, l.xyz)
             self._Xtree.append(Xt)
             ixx, iyy, izz, ixy, ixz, iyz = (float(t) for t in l.inertia)
             Ic = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
