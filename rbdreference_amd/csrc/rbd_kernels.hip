@@ -659,12 +659,17 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
 
 }  // namespace rbdk
 #include "rbd_idsva.h"
+#include "rbd_idsva_tree.h"
 namespace rbdk {
 #ifdef RBD_NO_IDSVA
 constexpr bool GRAD_USE_IDSVA = false;
 #else
 constexpr bool GRAD_USE_IDSVA = GRAD_IDSVA_OK;
 #endif
+// Trees whose column-recursion accumulators do not fit registers (Atlas) take the chain-by-chain
+// world-frame kernel (rbd_idsva_tree.h) in fp32; every eligible robot can be forced onto it with
+// RBD_GRAD_KERNEL=tree (tests, experiments), and back with RBD_GRAD_KERNEL=column.
+constexpr bool GRAD_TREE_DEFAULT = GRAD_TREE_OK && !GRAD_USE_IDSVA && !GRAD_ACC_IN_REGS;
 
 // ---------------------------------------------------------------------------------------------
 // minv: q -> Minv [B, n, n]                                                    (:630-806)
@@ -1066,6 +1071,34 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
   if (B == 0) return 0;
   if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
+  if constexpr (rbdk::GRAD_TREE_OK && (sizeof(T) == 4 || rbdm::N <= 12)) {   // fp64 x big tree: > 512 VGPRs, not built
+    using namespace rbdk;
+    static const int forced = [] {
+      const char* e = std::getenv("RBD_GRAD_KERNEL");
+      if (e && std::strcmp(e, "tree") == 0) return 1;
+      if (e && (std::strcmp(e, "column") == 0 || std::strcmp(e, "chain") == 0)) return -1;
+      return 0;
+    }();
+    constexpr size_t lds = tree_lds_bytes<T>();
+    const bool use_tree = forced > 0 || (forced == 0 && GRAD_TREE_DEFAULT && sizeof(T) == 4);
+    if (use_tree && lds <= 160 * 1024) {
+      const int64_t blocks = (B + 63) / 64;
+      if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+      int rc;
+      if (qdd) {
+        auto k = rnea_grad_tree_kernel<T, true>;
+        if ((rc = ensure_lds(k, lds)) != 0) return rc;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks, tree_n_roots()), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+      } else {
+        auto k = rnea_grad_tree_kernel<T, false>;
+        if ((rc = ensure_lds(k, lds)) != 0) return rc;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks, tree_n_roots()), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+      }
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad (tree kernel) launch");
+      return 0;
+    }
+  }
   if constexpr (rbdk::GRAD_USE_IDSVA) {
     // one lane per configuration (rbd_idsva.h)
     using namespace rbdk;
@@ -1159,7 +1192,6 @@ int crba_launch(const T* q, int64_t B, T* H, void* stream) {
 
 // ---- forward dynamics: compositions of the three kernels with fused epilogues ----
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-#if defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
 template <class T>
 int aba_launch(const T* q, const T* qd, const T* tau, T gravity, int64_t B, T* qdd, void* stream) {
   using namespace rbdk;
@@ -1178,7 +1210,6 @@ int aba_launch(const T* q, const T* qd, const T* tau, T gravity, int64_t B, T* q
   if (e != hipSuccess) return hip_fail(e, "rbd_aba launch");
   return 0;
 }
-#endif
 
 template <class T>
 struct FdWorkspace {
@@ -1246,7 +1277,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);
   } else {
     T* dc = reinterpret_cast<T*>(w + L.off_dcdu);
-    if ((rc = rnea_grad_launch1<T, true, false>(q, qd, qdd_buf, gravity, 0, B, nullptr, dc, stream, nullptr)) != 0) return rc;
+    if ((rc = rnea_grad_launch<T>(q, qd, qdd_buf, gravity, 0, B, nullptr, dc, stream)) != 0) return rc;
     const int64_t threads = B * 2 * N;
     hipLaunchKernelGGL(fd_grad_apply_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);
