@@ -20,6 +20,41 @@
 //               small root groups; otherwise phase A (minv_ia_kernel / minv_ia8_kernel) + phase B
 //               (minv_cols_kernel, one lane per COLUMN) through a [body][config][12] workspace.
 //   crba, rnea_fpass / rnea_bpass, forward_dynamics(_grad): further rows, same building blocks.
+// The library is built from several translation units of this one file (rbdreference_amd/build.py
+// compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
+// _MINV_F32, _MINV_F64, _FD_F32, _FD_F64, _PASS_F32, _PASS_F64 (each together with -DRBD_TU_SPLIT);
+// without RBD_TU_SPLIT everything is compiled in one unit.
+#if !defined(RBD_TU_SPLIT)
+#define RBD_TU_COMMON 1
+#define RBD_TU_RNEA_F32 1
+#define RBD_TU_RNEA_F64 1
+#define RBD_TU_GRAD_F32 1
+#define RBD_TU_GRAD_F64 1
+#define RBD_TU_MINV_F32 1
+#define RBD_TU_MINV_F64 1
+#define RBD_TU_FD_F32 1
+#define RBD_TU_FD_F64 1
+#define RBD_TU_PASS_F32 1
+#define RBD_TU_PASS_F64 1
+#endif
+
+// Which kernel families this unit needs (everything it does not need is dropped by the preprocessor,
+// so that build.py's object cache -- keyed by the preprocessed text -- survives unrelated edits).
+#if defined(RBD_TU_RNEA_F32) || defined(RBD_TU_RNEA_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#define RBD_NEED_RNEA 1
+#endif
+#if defined(RBD_TU_GRAD_F32) || defined(RBD_TU_GRAD_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#define RBD_NEED_GRAD 1
+#endif
+#if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#define RBD_NEED_MINV 1
+#endif
+#if defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#define RBD_NEED_FD 1
+#endif
+#if defined(RBD_TU_PASS_F32) || defined(RBD_TU_PASS_F64)
+#define RBD_NEED_PASS 1
+#endif
 #include "rbd_spatial.h"
 
 namespace rbdk {
@@ -106,6 +141,7 @@ constexpr size_t rnea_lds_bytes(bool vaf) {
   return (RNEA_PARK_VA && rnea_two_tiles<T>()) ? 2 * one : one;
 }
 
+#ifdef RBD_NEED_RNEA
 template <class T, bool HAS_QDD, bool WITH_VAF>
 __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                   const T* __restrict__ qdd, T grav, long long B,
@@ -247,6 +283,8 @@ __global__ __launch_bounds__(64) void rnea_bpass_kernel(const T* __restrict__ q,
   staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
 }
 
+#endif  // RBD_NEED_RNEA
+
 // ---------------------------------------------------------------------------------------------
 // rnea_grad: (q, qd, qdd) -> c [B,n] (optional), dc_du = [dc_dq | dc_dqd]  [B, n, 2n]  (:1345-1368)
 // ---------------------------------------------------------------------------------------------
@@ -313,6 +351,19 @@ constexpr int grad_cfgs() {
   return c;
 }
 
+// dc[i, c] is structurally non-zero only for related (ancestor/descendant) bodies.  Up to 72 such
+// pairs per lane are accumulated in registers; bigger robots accumulate in the LDS tile instead
+// (plain read-add-write: every address has exactly one owner lane; LDS float atomics measured ~4x
+// slower than that, DESIGN.md §3.1).
+constexpr int related_pairs() {
+  int k = 0;
+  for (int i = 0; i < N; ++i)
+    for (int c = 0; c < N; ++c) k += related(i, c) ? 1 : 0;
+  return k;
+}
+constexpr bool GRAD_ACC_IN_REGS = related_pairs() <= 72;
+
+#ifdef RBD_NEED_GRAD
 template <class T>
 RBD_DEV T from_odd_lane(T x);
 template <>
@@ -371,17 +422,6 @@ constexpr int grad_min_waves() {
   return sizeof(T) == 4 ? 2 : 1;
 #endif
 }
-// dc[i, c] is structurally non-zero only for related (ancestor/descendant) bodies.  Up to 72 such
-// pairs per lane are accumulated in registers; bigger robots accumulate in the LDS tile instead
-// (plain read-add-write: every address has exactly one owner lane; LDS float atomics measured ~4x
-// slower than that, DESIGN.md §3.1).
-constexpr int related_pairs() {
-  int k = 0;
-  for (int i = 0; i < N; ++i)
-    for (int c = 0; c < N; ++c) k += related(i, c) ? 1 : 0;
-  return k;
-}
-constexpr bool GRAD_ACC_IN_REGS = related_pairs() <= 72;
 
 
 // FDG = forward_dynamics_grad epilogue (:1376-1384): the accumulated dc_du block of each lane is
@@ -670,6 +710,7 @@ constexpr bool GRAD_USE_IDSVA = GRAD_IDSVA_OK;
 // world-frame kernel (rbd_idsva_tree.h) in fp32; every eligible robot can be forced onto it with
 // RBD_GRAD_KERNEL=tree (tests, experiments), and back with RBD_GRAD_KERNEL=column.
 constexpr bool GRAD_TREE_DEFAULT = GRAD_TREE_OK && !GRAD_USE_IDSVA && !GRAD_ACC_IN_REGS;
+#endif  // RBD_NEED_GRAD
 
 // ---------------------------------------------------------------------------------------------
 // minv: q -> Minv [B, n, n]                                                    (:630-806)
@@ -682,6 +723,9 @@ constexpr bool GRAD_TREE_DEFAULT = GRAD_TREE_OK && !GRAD_USE_IDSVA && !GRAD_ACC_
 // forward sweep recomputes F per body, so the reference's (n, 6, n) F tensor never exists.
 // ---------------------------------------------------------------------------------------------
 constexpr int MINV_WS = 12;   // scalars per (body, configuration) in the workspace
+constexpr int s_index(int i) { return (JTYPE[i] == 0 ? 0 : 3) + AXIS[i]; }
+
+#ifdef RBD_NEED_MINV
 
 template <class T>
 struct BodyCfg {
@@ -715,8 +759,6 @@ RBD_DEV void ws_read_lds(const T* recs, int i, T (&flat)[MINV_WS]) {
     sfor<0, VE>([&](auto E) { flat[k * VE + decltype(E)::value] = x[decltype(E)::value]; });
   });
 }
-
-constexpr int s_index(int i) { return (JTYPE[i] == 0 ? 0 : 3) + AXIS[i]; }
 
 template <class T>
 __global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, long long B, T* __restrict__ ws) {
@@ -902,31 +944,57 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
   }
 }
 
-// out[b] = -Minv[b] dc_du[b]  ([n, n] x [n, 2n]) for robots whose rnea_grad accumulates in LDS
-// (no fused epilogue): one thread per (configuration, output column), plain loops.
+#endif  // RBD_NEED_MINV
+
+#ifdef RBD_NEED_FD
+// out[b] = -Minv[b] dc_du[b]  ([n, n] x [n, 2n]) for robots without a fused -Minv epilogue.
+// One thread per (configuration, output column): its column of dc_du stays in registers (n coalesced
+// loads), the block's Minv matrices are staged in LDS once and read as broadcasts, so global traffic
+// is exactly Minv + dc_du in, dqdd_du out.
+constexpr int FDA_CPB = (256 / (2 * N)) > 0 ? 256 / (2 * N) : 1;     // configurations per block
 template <class T>
 __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict__ Minv, const T* __restrict__ dcdu,
                                                             long long B, T* __restrict__ out) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= B * 2 * N) return;
-  const long long b = t / (2 * N);
-  const int c = (int)(t - b * 2 * N);
-  const T* M = Minv + b * N * N;
-  const T* D = dcdu + b * 2 * N * N;
-  T* O = out + b * 2 * N * N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Ml = reinterpret_cast<T*>(smem_raw);                            // [FDA_CPB][N * N]
+  const long long cfg0 = (long long)blockIdx.x * FDA_CPB;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < FDA_CPB ? (int)rem : FDA_CPB;
+  {
+    const T* src = Minv + cfg0 * (N * N);
+    for (int g = threadIdx.x; g < nvalid * N * N; g += 256) Ml[g] = src[g];
+  }
+  __syncthreads();
+  const int cl = threadIdx.x / (2 * N);
+  const int c = threadIdx.x - cl * (2 * N);
+  if (cl >= nvalid) return;
+  const T* D = dcdu + (cfg0 + cl) * (2 * N * N);
+  T* O = out + (cfg0 + cl) * (2 * N * N);
+  const T* M = Ml + cl * (N * N);
+  T d[N];
+  sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; d[k] = D[k * 2 * N + c]; });
+#pragma clang loop unroll(disable)
   for (int i = 0; i < N; ++i) {
     T o = T(0);
-    for (int k = 0; k < N; ++k) o = fma_(-M[i * N + k], D[k * 2 * N + c], o);
+    sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(-M[i * N + k], d[k], o); });
     O[i * 2 * N + c] = o;
   }
 }
 
+#endif  // RBD_NEED_FD
+
 }  // namespace rbdk
-#include "rbd_minv_lane.h"
+#include "rbd_minv_lane.h"     // also defines MINV_LANE_OK, which sizes the workspaces (every unit)
+#ifdef RBD_NEED_MINV
 #include "rbd_minv_ia8.h"
+#endif
+#if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64)
 #include "rbd_crba.h"
+#endif
+#ifdef RBD_NEED_FD
 #include "rbd_aba.h"
-#if defined(RBD_TU_PASS_F32) || defined(RBD_TU_PASS_F64) || !defined(RBD_TU_SPLIT)
+#endif
+#ifdef RBD_NEED_PASS
 #include "rbd_passes.h"
 #endif
 namespace rbdk {
@@ -947,23 +1015,6 @@ constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
 #include <cstdlib>
 #include <cstring>
 
-// The library is built from several translation units of this one file (rbdreference_amd/build.py
-// compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
-// _MINV_F32, _MINV_F64, _FD_F32, _FD_F64, _PASS_F32, _PASS_F64 (each together with -DRBD_TU_SPLIT);
-// without RBD_TU_SPLIT everything is compiled in one unit.
-#if !defined(RBD_TU_SPLIT)
-#define RBD_TU_COMMON 1
-#define RBD_TU_RNEA_F32 1
-#define RBD_TU_RNEA_F64 1
-#define RBD_TU_GRAD_F32 1
-#define RBD_TU_GRAD_F64 1
-#define RBD_TU_MINV_F32 1
-#define RBD_TU_MINV_F64 1
-#define RBD_TU_FD_F32 1
-#define RBD_TU_FD_F64 1
-#define RBD_TU_PASS_F32 1
-#define RBD_TU_PASS_F64 1
-#endif
 
 // thread-local message buffer behind rbd_last_error(); one instance, owned by the COMMON unit
 extern "C" __attribute__((visibility("hidden"))) char* rbd_err_buf(void);
@@ -995,6 +1046,7 @@ int ensure_lds(K kernel, size_t bytes) {
   return 0;
 }
 
+#ifdef RBD_NEED_RNEA
 template <class T>
 int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f,
                 void* stream, int fpass_only = 0) {
@@ -1044,6 +1096,9 @@ int rnea_bpass_launch(const T* q, T* f, int64_t B, T* c, void* stream) {
   return 0;
 }
 
+#endif  // RBD_NEED_RNEA
+
+#ifdef RBD_NEED_GRAD
 // launches exactly one instantiation (the FD translation units use this to avoid compiling the
 // variants they never call)
 template <class T, bool HAS_QDD, bool FDG>
@@ -1125,6 +1180,9 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   }
 }
 
+#endif  // RBD_NEED_GRAD
+
+#ifdef RBD_NEED_MINV
 template <class T>
 int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspace, size_t wsb, void* stream,
                 const T* u = nullptr, const T* cbias = nullptr, T* qdd = nullptr) {
@@ -1172,6 +1230,9 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   }
 }
 
+#endif  // RBD_NEED_MINV
+
+#if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64)
 template <class T>
 int crba_launch(const T* q, int64_t B, T* H, void* stream) {
   using namespace rbdk;
@@ -1191,7 +1252,10 @@ int crba_launch(const T* q, int64_t B, T* H, void* stream) {
 }
 
 // ---- forward dynamics: compositions of the three kernels with fused epilogues ----
+#endif
+
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+#ifdef RBD_NEED_FD
 template <class T>
 int aba_launch(const T* q, const T* qd, const T* tau, T gravity, int64_t B, T* qdd, void* stream) {
   using namespace rbdk;
@@ -1211,6 +1275,8 @@ int aba_launch(const T* q, const T* qd, const T* tau, T gravity, int64_t B, T* q
   return 0;
 }
 
+#endif  // RBD_NEED_FD
+
 template <class T>
 struct FdWorkspace {
   size_t off_minv_ws, off_c, off_minv, off_qdd, off_dcdu, total;
@@ -1226,6 +1292,7 @@ struct FdWorkspace {
   }
 };
 
+#ifdef RBD_NEED_FD
 template <class T>
 int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, T* dqdd_du, bool want_grad,
               void* workspace, size_t wsb, void* stream) {
@@ -1278,15 +1345,18 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   } else {
     T* dc = reinterpret_cast<T*>(w + L.off_dcdu);
     if ((rc = rnea_grad_launch<T>(q, qd, qdd_buf, gravity, 0, B, nullptr, dc, stream)) != 0) return rc;
-    const int64_t threads = B * 2 * N;
-    hipLaunchKernelGGL(fd_grad_apply_kernel<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    static_assert(2 * N <= 256, "fd_grad_apply_kernel: one block must hold a configuration's 2n columns");
+    const int64_t ablocks = (B + FDA_CPB - 1) / FDA_CPB;
+    if (ablocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
+    if ((rc = ensure_lds(fd_grad_apply_kernel<T>, sizeof(T) * FDA_CPB * N * N)) != 0) return rc;
+    hipLaunchKernelGGL(fd_grad_apply_kernel<T>, dim3((unsigned)ablocks), dim3(256), sizeof(T) * FDA_CPB * N * N, (hipStream_t)stream,
                        (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad apply launch");
     return 0;
   }
 }
-
+#endif  // RBD_NEED_FD
 
 #if defined(RBD_TU_PASS_F32) || defined(RBD_TU_PASS_F64)
 // ---- per-pass entry points (rbd_passes.h) ------------------------------------------------------------
