@@ -258,6 +258,11 @@ def main():
             ms = time_kernel_ms(lambda: rbd.rnea(q, qd, qdd), 10, 2)
             extra["iiwa_rnea_cvaf_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3),
                                                         "alg_GBps": B * 22 * 7 * 4 / (ms * 1e-3) / 1e9}
+            ms = time_kernel_ms(lambda: rbd.aba(q, qd, qdd), 10, 2)
+            extra["iiwa_aba_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3),
+                                                  "alg_GBps": B * 4 * 7 * 4 / (ms * 1e-3) / 1e9}
+            ms = time_kernel_ms(lambda: rbd.forward_dynamics_grad(q, qd, qdd), 10, 2)
+            extra["iiwa_forward_dynamics_grad_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3)}
             try:
                 from rbdreference_amd import atlas_like, quadruped_like
                 ra = RBDReference(atlas_like(), build=False)
@@ -268,6 +273,9 @@ def main():
                 ms = time_kernel_ms(lambda: ra.rnea(qa, qda, qdda), 20, 3)
                 extra["cfg2_atlas_rnea_cvaf_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
                                                             "alg_GBps": 16384 * 2640 / (ms * 1e-3) / 1e9}
+                ms = time_kernel_ms(lambda: ra.rnea_grad(qa, qda, qdda, return_c=True), 20, 3)
+                extra["atlas_rnea_grad_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
+                                                       "alg_GBps": 16384 * (4 * 30 + 2 * 900) * 4 / (ms * 1e-3) / 1e9}
                 rq = RBDReference(quadruped_like(), build=False)
                 qq, qdq, qddq = make_inputs(65536, 12, 4, dev, torch.float64)
                 ms1 = time_kernel_ms(lambda: rq.rnea_grad(qq, qdq, qddq, return_c=True), 10, 2)
