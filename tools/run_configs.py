@@ -11,7 +11,7 @@ def inputs(B, n, seed, dt):
 which = sys.argv[1:] or ["atlas", "quad", "iiwa"]
 if "atlas" in which:
     r = RBDReference(atlas_like(), build=False); q, qd, qdd = inputs(16384, 30, 2, torch.float32)
-    for _ in range(REPS): r.minv(q); r.rnea(q, qd, qdd)
+    for _ in range(REPS): r.minv(q); r.rnea(q, qd, qdd); r.rnea_grad(q, qd, qdd, return_c=True); r.aba(q, qd, qdd)
 if "quad" in which:
     r = RBDReference(quadruped_like(), build=False); q, qd, qdd = inputs(65536, 12, 4, torch.float64)
     for _ in range(REPS): r.rnea_grad(q, qd, qdd, return_c=True); r.minv(q)
@@ -19,5 +19,6 @@ if "iiwa" in which:
     r = RBDReference(iiwa_like(), build=False); q, qd, qdd = inputs(4096, 7, 1, torch.float32)
     for _ in range(REPS): r.rnea(q, qd, qdd); r.rnea_grad(q, qd, qdd, return_c=True); r.minv(q)
     q, qd, qdd = inputs(1 << 20, 7, 3, torch.float32)
-    for _ in range(REPS): r.rnea(q, qd, qdd); r.minv(q)
+    for _ in range(REPS): r.rnea(q, qd, qdd); r.minv(q); r.aba(q, qd, qdd)
+    for _ in range(max(2, REPS // 4)): r.forward_dynamics_grad(q, qd, qdd)
 torch.cuda.synchronize()
