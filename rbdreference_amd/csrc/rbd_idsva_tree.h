@@ -377,7 +377,8 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_tree_kernel(const T* __restri
   sfor_down<0, N>([&](auto H_) {
     constexpr int h = decltype(H_)::value;
     if constexpr (is_chain_head(h)) {
-     if (TP.rootidx[h] == myroot) {
+     constexpr int hroot = TP.rootidx[h];
+     if (hroot == myroot) {
       constexpr int leaf = chain_leaf(h);
       // ---- inputs and trig of the root path of this chain ------------------------------------------
       JTrig<T> tr[N];

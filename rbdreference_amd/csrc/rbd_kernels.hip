@@ -812,62 +812,97 @@ __global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, lo
 #ifndef MINV_COLS_MIN_WAVES
 #define MINV_COLS_MIN_WAVES 4
 #endif
-constexpr int MINV_LC = (N <= 8) ? 8 : (N <= 16) ? 16 : (N <= 32) ? 32 : 64;   // lanes per configuration
-constexpr int MINV_CPB = 64 / MINV_LC;                                         // configurations per wave
-constexpr int MINV_TS = (N * N) | 1;                                           // LDS tile stride (odd)
+// Phase B works per GROUP (root subtree): Minv is block-diagonal over groups, so the columns of a
+// group only ever meet the bodies of that group.  Every group gets its own blocks (lanes per
+// configuration = the group's column count rounded up to 8 / 16 / 32 / 64), which cuts the serial
+// body loop of a wave from n to the group's size (Atlas: 30 -> 18 / 6 / 6).
+constexpr int minv_lc(int rows) { return rows <= 8 ? 8 : rows <= 16 ? 16 : rows <= 32 ? 32 : 64; }
+constexpr int minv_cpb(int rt) { return 64 / minv_lc(grp_rows(rt)); }              // configurations per wave
+constexpr int minv_ts(int rt) { return (grp_rows(rt) * N) | 1; }                   // LDS tile stride (odd)
+constexpr int grp_index(int rt) {   // ordinal of group head rt
+  int k = 0;
+  for (int x = 0; x < rt; ++x) k += grp_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int n_groups() {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += grp_head(x) ? 1 : 0;
+  return k;
+}
+template <class T>
+constexpr size_t minv_cols_lds_bytes() {
+  size_t m = 0;
+  for (int rt = 0; rt < N; ++rt)
+    if (grp_head(rt)) {
+      const size_t x = sizeof(T) * ((size_t)minv_cpb(rt) * minv_ts(rt) + (size_t)minv_cpb(rt) * grp_rows(rt) * MINV_WS);
+      m = x > m ? x : m;
+    }
+  return m;
+}
+inline long long minv_cols_blocks(long long B) {
+  long long nb = 0;
+  for (int rt = 0; rt < N; ++rt)
+    if (grp_head(rt)) nb += (B + minv_cpb(rt) - 1) / minv_cpb(rt);
+  return nb;
+}
 constexpr unsigned long long subtree_mask(int i) {
   unsigned long long m = 0;
   for (int j = 0; j < N; ++j) m |= is_anc_or_self(i, j) ? (1ull << j) : 0ull;
   return m;
 }
 
-template <class T>
-__global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
-                                                       T* __restrict__ Minv, const T* __restrict__ u_in,
-                                                       const T* __restrict__ c_in, T* __restrict__ qdd_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* wsl = reinterpret_cast<T*>(smem_raw);                 // [MINV_CPB][N][MINV_WS] per-body records
-  T* tile = wsl + MINV_CPB * N * MINV_WS;                  // [MINV_CPB][MINV_TS] output image
+template <class T, int RT>
+RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T* __restrict__ Minv,
+                             const T* __restrict__ u_in, const T* __restrict__ c_in, T* __restrict__ qdd_out,
+                             long long blk, unsigned char* smem_raw) {
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT);
+  constexpr int LC = minv_lc(rows), CPB = 64 / LC, TS = minv_ts(RT);
+  T* wsl = reinterpret_cast<T*>(smem_raw);                 // [CPB][rows][MINV_WS] per-body records
+  T* tile = wsl + CPB * rows * MINV_WS;                    // [CPB][TS] image of the group's rows (full width n)
   const int lane = threadIdx.x;
-  const int j = lane % MINV_LC;          // this lane's column
-  const int slot = lane / MINV_LC;
-  const long long cfg0 = (long long)blockIdx.x * MINV_CPB;
+  const int jl = lane % LC;              // this lane's column within the group
+  const int j = row0 + jl;               // ... and in the matrix
+  const int slot = lane / LC;
+  const long long cfg0 = blk * CPB;
   const long long rem = B - cfg0;
-  const int nvalid = rem < MINV_CPB ? (int)rem : MINV_CPB;
+  const int nvalid = rem < CPB ? (int)rem : CPB;
 
   // stage the block's {U, 1/D, sin, cos} records in LDS once (both sweeps read them; every lane of a
-  // configuration reads the same record => LDS broadcast instead of 2 x N dependent L2 round trips)
+  // configuration reads the same record => LDS broadcast instead of 2 x n dependent L2 round trips)
   {
     constexpr int VE = 16 / sizeof(T);
     constexpr int VPB = MINV_WS / VE;                      // 16-byte pieces per record
     typedef T V __attribute__((ext_vector_type(VE)));
     V* dst = reinterpret_cast<V*>(wsl);
 #pragma unroll 2
-    for (int idx = lane; idx < MINV_CPB * N * VPB; idx += 64) {
+    for (int idx = lane; idx < CPB * rows * VPB; idx += 64) {
       const int piece = idx % VPB;
       const int rec = idx / VPB;
-      const int body = rec % N;
-      const int cs = rec / N;
+      const int body = row0 + rec % rows;
+      const int cs = rec / rows;
       const long long bb = cfg0 + (cs < nvalid ? cs : nvalid - 1);
       dst[idx] = reinterpret_cast<const V*>(ws + ((long long)body * B + bb) * MINV_WS)[piece];
     }
+    if constexpr (rows != N) {   // columns outside the group are structural zeros
+      for (int g = lane; g < CPB * TS; g += 64) tile[g] = T(0);
+    }
   }
   __syncthreads();
-  const T* myws = wsl + slot * N * MINV_WS;
+  const T* myws = wsl + (slot * rows - row0) * MINV_WS;   // myws + i * MINV_WS = record of body i
 
   T mcol[N];
   T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   // Records are read one body ahead of their use; pin6() at the end of each body is an ordering
-  // point that keeps the compiler from hoisting ALL N record reads to the top of the kernel (which
-  // costs 9 N VGPRs and spills: the instruction selector otherwise schedules every LDS read first).
+  // point that keeps the compiler from hoisting ALL record reads to the top of the kernel (which
+  // costs 9 n VGPRs and spills: the instruction selector otherwise schedules every LDS read first).
   T rec[N][MINV_WS];
-  ws_read_lds(myws, N - 1, rec[N - 1]);
+  ws_read_lds(myws, row0 + rows - 1, rec[row0 + rows - 1]);
   // ---- backward sweep (:665-726), column j -----------------------------------------------------
-  sfor_down<0, N>([&](auto I) {
+  sfor_down<row0, row0 + rows>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int p = PARENT[i];
     constexpr unsigned long long mask = subtree_mask(i);
-    if constexpr (i > 0) ws_read_lds(myws, i - 1, rec[i - 1]);
+    if constexpr (i > row0) ws_read_lds(myws, i - 1, rec[i - 1]);
     BodyCfg<T> bc;
     sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = rec[i][decltype(R)::value]; });
     bc.Dinv = rec[i][6]; bc.s = rec[i][7]; bc.c = rec[i][8];
@@ -887,15 +922,15 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
   // ---- forward sweep (:760-781), column j ------------------------------------------------------
   T Ff[N][6];
   // (the memory clobbers of pin6() also stop the compiler from forwarding the backward sweep's
-  // record reads to the forward sweep, which would keep all 9 N values live in between)
+  // record reads to the forward sweep, which would keep all 9 n values live in between)
   const T* myws2 = myws;
   T rec2[N][MINV_WS];
-  ws_read_lds(myws2, 0, rec2[0]);
-  sfor<0, N>([&](auto I) {
+  ws_read_lds(myws2, row0, rec2[row0]);
+  sfor<row0, row0 + rows>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int p = PARENT[i];
     constexpr int si = s_index(i);
-    if constexpr (i + 1 < N) ws_read_lds(myws2, i + 1, rec2[i + 1]);
+    if constexpr (i + 1 < row0 + rows) ws_read_lds(myws2, i + 1, rec2[i + 1]);
     if constexpr (p < 0) {
       sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
       Ff[i][si] = mcol[i];                                                                        // :781
@@ -911,10 +946,10 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
     }
     pin6(Ff[i]);
   });
-  // ---- symmetrise (:799-804) through LDS, then stream the tile out ------------------------------
-  T* myt = tile + slot * MINV_TS;
-  if (j < N) {
-    sfor<0, N>([&](auto I) {
+  // ---- symmetrise (:799-804) through LDS, then stream the group's rows out -----------------------
+  T* myt = tile + slot * TS - row0 * N;                    // myt[i * N + c], rows of this group
+  if (jl < rows) {
+    sfor<row0, row0 + rows>([&](auto I) {
       constexpr int i = decltype(I)::value;
       if (i <= j) myt[i * N + j] = mcol[i];
       if (i < j) myt[j * N + i] = sel(dense != 0, mcol[i], T(0));
@@ -924,24 +959,52 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
   if (qdd_out != nullptr) {
     // forward_dynamics epilogue (:1371-1374): qdd = Minv (u - c); lane j owns row j of the dense tile.
     // (u - c) is parked in the record area, which both sweeps have finished reading.
-    T* tau = wsl + slot * N;
-    if (j < N && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
+    T* tau = wsl + slot * rows - row0;                     // tau[k], k in the group
+    if (jl < rows && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
     __syncthreads();
-    if (j < N && slot < nvalid) {
+    if (jl < rows && slot < nvalid) {
       T o = T(0);
-      sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[j * N + k], tau[k], o); });
+      sfor<row0, row0 + rows>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[j * N + k], tau[k], o); });
       qdd_out[(cfg0 + slot) * N + j] = o;
     }
   }
   if (Minv != nullptr) {
-    T* gdst = Minv + cfg0 * (N * N);
-    const int total = nvalid * N * N;
+    constexpr int RW = rows * N;
+    T* gdst = Minv + cfg0 * (N * N) + row0 * N;
+    const int total = nvalid * RW;
 #pragma unroll 4
     for (int g = lane; g < total; g += 64) {
-      int cfg = g / (N * N);
-      gdst[g] = tile[g + cfg * (MINV_TS - N * N)];
+      const int cfg = g / RW;
+      const int r2 = g - cfg * RW;
+      gdst[(long long)cfg * (N * N) + r2] = tile[cfg * TS + r2];
     }
   }
+}
+
+template <class T>
+__global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
+                                                       T* __restrict__ Minv, const T* __restrict__ u_in,
+                                                       const T* __restrict__ c_in, T* __restrict__ qdd_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // 1-D grid: the blocks of group 0, then those of group 1, ... (each group has its own
+  // configurations-per-block count)
+  long long blk = blockIdx.x;
+  bool done = false;
+  sfor<0, N>([&](auto Rt) {
+    constexpr int rt = decltype(Rt)::value;
+    if constexpr (grp_head(rt)) {
+      constexpr int cpb = minv_cpb(rt);   // constexpr on purpose: as a plain call the tree walk ran at run time
+      const long long nb = (B + cpb - 1) / cpb;
+      if (!done) {
+        if (blk < nb) {
+          minv_cols_group<T, rt>(ws, B, dense, Minv, u_in, c_in, qdd_out, blk, smem_raw);
+          done = true;
+        } else {
+          blk -= nb;
+        }
+      }
+    }
+  });
 }
 
 #endif  // RBD_NEED_MINV
@@ -1206,7 +1269,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   const size_t need = (size_t)B * N * MINV_WS * sizeof(T);
   if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
-  const int64_t blocksA = (B + 63) / 64, blocksB = (B + MINV_CPB - 1) / MINV_CPB;
+  const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B);
   if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   hipStream_t s = (hipStream_t)stream;
   T* ws = reinterpret_cast<T*>(workspace);
@@ -1215,11 +1278,11 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (B >= 64 * 1024 * 4 || std::getenv("RBD_MINV_IA1") != nullptr) {
     hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
   } else {
-    hipLaunchKernelGGL(minv_ia8_kernel<T>, dim3((unsigned)((B + 7) / 8)), dim3(64), 0, s, q, (long long)B, ws);
+    hipLaunchKernelGGL(minv_ia8_kernel<T>, dim3((unsigned)((B + 7) / 8), n_groups()), dim3(64), 0, s, q, (long long)B, ws);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase A launch");
-  const size_t lds = sizeof(T) * ((size_t)MINV_CPB * MINV_TS + (size_t)MINV_CPB * N * MINV_WS);
+  constexpr size_t lds = minv_cols_lds_bytes<T>();
   auto k = minv_cols_kernel<T>;
   int rc;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;

@@ -71,8 +71,16 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
   // configuration; read up front, the 6 N values spilled.)
   for (int k = lane; k < N * 36; k += 64) im_lds[k] = T(IM[k / 36][k % 36]);
   __syncthreads();
+  // independent root subtrees (groups) run in separate blocks: blockIdx.y picks the group, which
+  // shortens the serial body chain of a wave from n to the group's size
+  const int gsel = blockIdx.y;
+  sfor<0, N>([&](auto Rt_) {
+   constexpr int rt = decltype(Rt_)::value;
+   if constexpr (grp_head(rt)) {
+   constexpr int gi = grp_index(rt);   // constexpr on purpose (a plain call would walk the tree at run time)
+   if (gi == gsel) {
   T IAc[N][6];
-  sfor_down<0, N>([&](auto I) {
+  sfor_down<grp_row0(rt), grp_row0(rt) + grp_rows(rt)>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int p = PARENT[i];
     constexpr int si = s_index(i);
@@ -127,6 +135,9 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
       });
       pin6(IAc[p]);   // ordering point: keeps the bodies in program order (bounds live registers)
     }
+  });
+   }
+   }
   });
 }
 
