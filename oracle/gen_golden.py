@@ -6,7 +6,7 @@ objects (the same objects the HIP path packs), and every pass of the rnea / rnea
 is run one configuration at a time, exactly as a user of the reference would.  Inputs and outputs
 are stored as small float64 fixtures; the reference itself never leaves this container.
 
-    python oracle/gen_golden.py            # rewrites tests/golden/golden_<robot>.npz
+    python oracle/gen_golden.py [robot ...]   # rewrites tests/golden/golden_<robot>.npz (all by default)
 
 Fixture contents (S = number of samples, n = DoF):
     q, qd, qdd                      [S, n]      inputs   (numpy default_rng(seed))
@@ -116,6 +116,12 @@ def main():
     robots.append(("random_prismatic_n6", random_tree([-1, 0, 1, 2, 2, 4], seed=11,
                                                        prismatic_every=3,
                                                        name="random_prismatic_n6"), 202))
+    # two roots whose subtrees INTERLEAVE in the numbering (0: {0,2,4,5,7}, 1: {1,3,6}) and a branch
+    robots.append(("random_forest_n8", random_tree([-1, -1, 0, 1, 2, 0, 3, 5], seed=33,
+                                                    name="random_forest_n8"), 204))
+    only = set(sys.argv[1:])
+    if only:
+        robots = [r for r in robots if r[0] in only]
     for nm, robot, seed in robots:
         n = robot.get_num_bodies()
         S = N_SAMPLES if n <= 12 else 8

@@ -40,6 +40,8 @@ def make_robot(name):
         return random_tree([-1, 0, 1, 2, 3, 4, 5], seed=21, name=name)
     if name == "random_prismatic_n6":
         return random_tree([-1, 0, 1, 2, 2, 4], seed=11, prismatic_every=3, name=name)
+    if name == "random_forest_n8":      # interleaved root subtrees + a branch (no per-root groups)
+        return random_tree([-1, -1, 0, 1, 2, 0, 3, 5], seed=33, name=name)
     raise KeyError(name)
 
 
