@@ -12,6 +12,7 @@ import shutil
 import subprocess
 import sys
 import threading
+import time
 from typing import Optional
 
 from .packer import PackedModel, emit_header, pack_robot
@@ -111,7 +112,10 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
         cmd = [*base, "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        t0 = time.time()
         r = _run(cmd, f"{m.name} {tu}")
+        if os.environ.get("RBD_BUILD_TIMES"):
+            print(f"[build] {m.name:24s} {tu:9s} {time.time() - t0:7.1f} s", file=sys.stderr)
         if verbose and r.stderr:
             print(r.stderr, file=sys.stderr)
         os.replace(obj + f".{os.getpid()}.tmp", obj)

@@ -40,13 +40,13 @@
 
 // Which kernel families this unit needs (everything it does not need is dropped by the preprocessor,
 // so that build.py's object cache -- keyed by the preprocessed text -- survives unrelated edits).
-#if defined(RBD_TU_RNEA_F32) || defined(RBD_TU_RNEA_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#if defined(RBD_TU_RNEA_F32) || defined(RBD_TU_RNEA_F64)
 #define RBD_NEED_RNEA 1
 #endif
 #if defined(RBD_TU_GRAD_F32) || defined(RBD_TU_GRAD_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
 #define RBD_NEED_GRAD 1
 #endif
-#if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64)
 #define RBD_NEED_MINV 1
 #endif
 #if defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
@@ -1089,6 +1089,16 @@ extern "C" char* rbd_err_buf(void) {
 #endif
 constexpr size_t RBD_ERR_LEN = 512;
 
+// The forward-dynamics units reuse the kernels of the RNEA / MINV / GRAD units through these entry
+// points instead of instantiating the same templates a second time (Atlas: the fp64 gradient kernel
+// alone costs 200 s of compile time).  rbd_minv_fd_* = rbd_minv_* plus the fused qdd = Minv (u - c).
+extern "C" {
+__attribute__((visibility("hidden"))) int rbd_minv_fd_f32(const float* q, int64_t B, float* Minv, void* workspace, size_t wsb,
+                                                          void* stream, const float* u, const float* c, float* qdd);
+__attribute__((visibility("hidden"))) int rbd_minv_fd_f64(const double* q, int64_t B, double* Minv, void* workspace, size_t wsb,
+                                                          void* stream, const double* u, const double* c, double* qdd);
+}
+
 namespace {
 int fail(int code, const char* msg) {
   std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s", msg);
@@ -1183,14 +1193,16 @@ int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_
   return 0;
 }
 
-template <class T>
-int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
-                     T* c, T* dc_du, void* stream) {
-  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
-  if (B == 0) return 0;
-  if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
-  if constexpr (rbdk::GRAD_TREE_OK && (sizeof(T) == 4 || rbdm::N <= 12)) {   // fp64 x big tree: > 512 VGPRs, not built
-    using namespace rbdk;
+// One instantiation per (T, HAS_QDD): the forward-dynamics units only ever need HAS_QDD = true.
+template <class T, bool HAS_QDD>
+int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                       T* c, T* dc_du, void* stream) {
+  using namespace rbdk;
+  // fp32 robots whose default is the tree kernel never build the column kernel (Atlas: 404 VGPRs of
+  // code nobody runs); fp64 x big tree would need > 512 VGPRs and is not built either.
+  constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
+  constexpr bool TREE_BUILT = GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
+  if constexpr (TREE_BUILT) {
     static const int forced = [] {
       const char* e = std::getenv("RBD_GRAD_KERNEL");
       if (e && std::strcmp(e, "tree") == 0) return 1;
@@ -1198,49 +1210,48 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
       return 0;
     }();
     constexpr size_t lds = tree_lds_bytes<T>();
-    const bool use_tree = forced > 0 || (forced == 0 && GRAD_TREE_DEFAULT && sizeof(T) == 4);
+    static_assert(!TREE_ONLY || lds <= 160 * 1024, "tree kernel is the only gradient kernel of this robot but does not fit LDS");
+    const bool use_tree = TREE_ONLY || forced > 0;
     if (use_tree && lds <= 160 * 1024) {
       const int64_t blocks = (B + 63) / 64;
       if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
       int rc;
-      if (qdd) {
-        auto k = rnea_grad_tree_kernel<T, true>;
-        if ((rc = ensure_lds(k, lds)) != 0) return rc;
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks, tree_n_roots()), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
-      } else {
-        auto k = rnea_grad_tree_kernel<T, false>;
-        if ((rc = ensure_lds(k, lds)) != 0) return rc;
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks, tree_n_roots()), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
-      }
+      auto k = rnea_grad_tree_kernel<T, HAS_QDD>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks, tree_n_roots()), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad (tree kernel) launch");
       return 0;
     }
   }
-  if constexpr (rbdk::GRAD_USE_IDSVA) {
+  if constexpr (TREE_ONLY) {
+    return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: no kernel");   // unreachable (static_assert above)
+  } else if constexpr (GRAD_USE_IDSVA) {
     // one lane per configuration (rbd_idsva.h)
-    using namespace rbdk;
     const int64_t blocks = (B + 63) / 64;
     if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
     const size_t lds = sizeof(T) * (size_t)64 * GRAD_TS;
     if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
     int rc;
-    if (qdd) {
-      auto k = rnea_grad_idsva_kernel<T, true>;
-      if ((rc = ensure_lds(k, lds)) != 0) return rc;
-      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du, (const T*)nullptr);
-    } else {
-      auto k = rnea_grad_idsva_kernel<T, false>;
-      if ((rc = ensure_lds(k, lds)) != 0) return rc;
-      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du, (const T*)nullptr);
-    }
+    auto k = rnea_grad_idsva_kernel<T, HAS_QDD>;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du, (const T*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
     return 0;
   } else {
-    if (qdd) return rnea_grad_launch1<T, true, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
-    return rnea_grad_launch1<T, false, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
+    return rnea_grad_launch1<T, HAS_QDD, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
   }
+}
+
+template <class T>
+int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                     T* c, T* dc_du, void* stream) {
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
+  if (qdd) return rnea_grad_launch_q<T, true>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+  return rnea_grad_launch_q<T, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
 }
 
 #endif  // RBD_NEED_GRAD
@@ -1375,21 +1386,14 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   T* Mi = reinterpret_cast<T*>(w + L.off_minv);
   T* qdd_buf = qdd ? qdd : reinterpret_cast<T*>(w + L.off_qdd);
   int rc;
-  // c = rnea(q, qd) with qdd = None (:1372)
-  {
-    const int64_t blocks = (B + 63) / 64;
-    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B too large");
-    auto k = rnea_kernel<T, false, false>;
-    const size_t lds = rnea_lds_bytes<T>(false);
-    if ((rc = ensure_lds(k, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)nullptr, gravity,
-                       (long long)B, c, (T*)nullptr, (T*)nullptr, (T*)nullptr, 0);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics rnea launch");
-  }
-  // qdd = Minv (u - c) (:1373-1374); Minv itself is kept only when the gradient needs it
-  if ((rc = minv_launch<T>(q, B, 1, want_grad ? Mi : nullptr, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T),
-                           stream, u, c, qdd_buf)) != 0) return rc;
+  // c = rnea(q, qd) with qdd = None (:1372), c-only kernel of the RNEA unit
+  if constexpr (sizeof(T) == 4) rc = rbd_rnea_f32((const float*)q, (const float*)qd, nullptr, (float)gravity, B, (float*)c, nullptr, nullptr, nullptr, stream);
+  else rc = rbd_rnea_f64((const double*)q, (const double*)qd, nullptr, (double)gravity, B, (double*)c, nullptr, nullptr, nullptr, stream);
+  if (rc != 0) return rc;
+  // qdd = Minv (u - c) (:1373-1374), fused into the last phase of minv (MINV unit)
+  if constexpr (sizeof(T) == 4) rc = rbd_minv_fd_f32((const float*)q, B, (float*)Mi, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T), stream, (const float*)u, (const float*)c, (float*)qdd_buf);
+  else rc = rbd_minv_fd_f64((const double*)q, B, (double*)Mi, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T), stream, (const double*)u, (const double*)c, (double*)qdd_buf);
+  if (rc != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
   if constexpr (GRAD_USE_IDSVA && grad_max_rows() == N) {
@@ -1407,7 +1411,10 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);
   } else {
     T* dc = reinterpret_cast<T*>(w + L.off_dcdu);
-    if ((rc = rnea_grad_launch<T>(q, qd, qdd_buf, gravity, 0, B, nullptr, dc, stream)) != 0) return rc;
+    // plain rnea_grad of the GRAD unit, then the -Minv product
+    if constexpr (sizeof(T) == 4) rc = rbd_rnea_grad_f32((const float*)q, (const float*)qd, (const float*)qdd_buf, (float)gravity, 0, B, nullptr, (float*)dc, stream);
+    else rc = rbd_rnea_grad_f64((const double*)q, (const double*)qd, (const double*)qdd_buf, (double)gravity, 0, B, nullptr, (double*)dc, stream);
+    if (rc != 0) return rc;
     static_assert(2 * N <= 256, "fd_grad_apply_kernel: one block must hold a configuration's 2n columns");
     const int64_t ablocks = (B + FDA_CPB - 1) / FDA_CPB;
     if (ablocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
@@ -1568,6 +1575,10 @@ int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void*
                  size_t workspace_bytes, void* stream) {
   return minv_launch<float>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
 }
+int rbd_minv_fd_f32(const float* q, int64_t B, float* Minv, void* workspace, size_t wsb, void* stream,
+                    const float* u, const float* c, float* qdd) {
+  return minv_launch<float>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
+}
 #endif
 #ifdef RBD_TU_FD_F32
 int rbd_aba_f32(const float* q, const float* qd, const float* tau, float gravity, int64_t B, float* qdd, void* stream) {
@@ -1599,6 +1610,10 @@ int rbd_forward_dynamics_grad_f64(const double* q, const double* qd, const doubl
 int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
                  size_t workspace_bytes, void* stream) {
   return minv_launch<double>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+}
+int rbd_minv_fd_f64(const double* q, int64_t B, double* Minv, void* workspace, size_t wsb, void* stream,
+                    const double* u, const double* c, double* qdd) {
+  return minv_launch<double>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
 }
 #endif
 
