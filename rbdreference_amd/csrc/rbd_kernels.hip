@@ -327,6 +327,16 @@ constexpr int grp_next(int rt) {   // next group head after rt, -1 if none
     if (grp_head(r)) return r;
   return -1;
 }
+constexpr int grp_index(int rt) {   // ordinal of group head rt
+  int k = 0;
+  for (int x = 0; x < rt; ++x) k += grp_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int n_groups() {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += grp_head(x) ? 1 : 0;
+  return k;
+}
 constexpr int grad_max_rows() {
   int m = 0;
   for (int r = 0; r < N; ++r)
@@ -819,16 +829,6 @@ __global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, lo
 constexpr int minv_lc(int rows) { return rows <= 8 ? 8 : rows <= 16 ? 16 : rows <= 32 ? 32 : 64; }
 constexpr int minv_cpb(int rt) { return 64 / minv_lc(grp_rows(rt)); }              // configurations per wave
 constexpr int minv_ts(int rt) { return (grp_rows(rt) * N) | 1; }                   // LDS tile stride (odd)
-constexpr int grp_index(int rt) {   // ordinal of group head rt
-  int k = 0;
-  for (int x = 0; x < rt; ++x) k += grp_head(x) ? 1 : 0;
-  return k;
-}
-constexpr int n_groups() {
-  int k = 0;
-  for (int x = 0; x < N; ++x) k += grp_head(x) ? 1 : 0;
-  return k;
-}
 template <class T>
 constexpr size_t minv_cols_lds_bytes() {
   size_t m = 0;
@@ -1342,8 +1342,8 @@ int aba_launch(const T* q, const T* qd, const T* tau, T gravity, int64_t B, T* q
   constexpr size_t lds = aba_lds_bytes<T>();
   if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_aba: per-body state does not fit LDS for this robot size");
   if (int rc = ensure_lds(aba_kernel<T>, lds)) return rc;
-  hipLaunchKernelGGL(aba_kernel<T>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, tau, gravity,
-                     (long long)B, qdd);
+  hipLaunchKernelGGL(aba_kernel<T>, dim3((unsigned)blocks, ABA_PARK ? n_groups() : 1), dim3(64), lds, (hipStream_t)stream, q, qd, tau,
+                     gravity, (long long)B, qdd);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_aba launch");
   return 0;
