@@ -379,30 +379,47 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
       // c_j and the t-vectors (:1481-1484)
       const T cj = dot6(Sv[j], fC);
       if (c_out != nullptr && lane < nvalid) c_out[b * N + j] = cj;
-      T y1[6], y2[6], y3[6], s1[6], s2[6], z1[6], z2[6], zf[6];
+      T y1[6], y3[6], s1[6], z1[6], zf[6];
       rin_apply(IC, Sv[j], y1);
-      rin_apply(IC, Pd[j], y2);
       rin_apply(IC, Pdd[j], y3);
       sym_apply(SC, Sv[j], s1);
-      sym_apply(SC, Pd[j], s2);
       fxv<false>(Sv[j], pmC, z1);
-      fxv<false>(Pd[j], pmC, z2);
       fxv<false>(Sv[j], fC, zf);
       T t1[6], t2[6], t3[6], t4[6];
-      sfor<0, 6>([&](auto R_) {
-        constexpr int r = decltype(R_)::value;
-        t1[r] = y1[r];
-        t4[r] = s1[r] - z1[r];
-        t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
-        t2[r] = fma_(T(2), y2[r], s1[r] + z1[r]);
-      });
+      if constexpr (PARENT[j] < 0) {
+        // psid of a root is identically zero (v_parent = 0): its three products drop out
+        sfor<0, 6>([&](auto R_) {
+          constexpr int r = decltype(R_)::value;
+          t1[r] = y1[r];
+          t4[r] = s1[r] - z1[r];
+          t3[r] = y3[r] + zf[r];
+          t2[r] = s1[r] + z1[r];
+        });
+      } else {
+        T y2[6], s2[6], z2[6];
+        rin_apply(IC, Pd[j], y2);
+        sym_apply(SC, Pd[j], s2);
+        fxv<false>(Pd[j], pmC, z2);
+        sfor<0, 6>([&](auto R_) {
+          constexpr int r = decltype(R_)::value;
+          t1[r] = y1[r];
+          t4[r] = s1[r] - z1[r];
+          t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
+          t2[r] = fma_(T(2), y2[r], s1[r] + z1[r]);
+        });
+      }
       // all pairs (j, jj) with jj an ancestor-or-self of j (chain: row0 .. j)
       sfor<row0, j + 1>([&](auto JJ) {
         constexpr int jj = decltype(JJ)::value;
-        T dq_ij = fma_(t4[0], Pd[jj][0], fma_(t4[1], Pd[jj][1], fma_(t4[2], Pd[jj][2], fma_(t4[3], Pd[jj][3], fma_(t4[4], Pd[jj][4], t4[5] * Pd[jj][5])))));
-        dq_ij += dot6(t1, Pdd[jj]);
-        T dqd_ij = dot6(t4, Sv[jj]);
-        dqd_ij = fma_(T(2), dot6(t1, Pd[jj]), dqd_ij);
+        T dq_ij, dqd_ij;
+        if constexpr (PARENT[jj] < 0) {
+          // root ancestor: psid = 0 and psidd = a_base x S = (0, 0, 0, g S_y, -g S_x, 0)
+          dq_ij = fma_(t1[3], Pdd[jj][3], t1[4] * Pdd[jj][4]);
+          dqd_ij = dot6(t4, Sv[jj]);
+        } else {
+          dq_ij = dot6(t4, Pd[jj]) + dot6(t1, Pdd[jj]);
+          dqd_ij = fma_(T(2), dot6(t1, Pd[jj]), dot6(t4, Sv[jj]));
+        }
         if constexpr (jj == j) dqd_ij += sel(use_damping != 0, T(DAMPING[j]), T(0));   // :1336-1341
         my[j * GRAD_ROW + jj] = dq_ij;
         my[j * GRAD_ROW + N + jj] = dqd_ij;
