@@ -66,12 +66,43 @@ def _sources_digest(m: PackedModel, flags) -> str:
 
 TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64",
                      "FD_F32", "FD_F64", "PASS_F32", "PASS_F64"]
-_HIPCC_SLOTS = threading.BoundedSemaphore(max(1, (os.cpu_count() or 2)))
+class _PrioritySlots:
+    """At most `n` hipcc processes at a time; when one finishes, the waiting job with the highest
+    cost estimate goes next (longest-first keeps the one 3-minute unit of a 30-body robot from
+    starting last and stretching the whole build)."""
+
+    def __init__(self, n: int):
+        self.free = n
+        self.cv = threading.Condition()
+        self.waiting = []          # costs of the jobs that are waiting
+
+    def acquire(self, cost: float):
+        with self.cv:
+            self.waiting.append(cost)
+            while not (self.free > 0 and cost >= max(self.waiting)):
+                self.cv.wait()
+            self.waiting.remove(cost)
+            self.free -= 1
+            self.cv.notify_all()
+
+    def release(self):
+        with self.cv:
+            self.free += 1
+            self.cv.notify_all()
 
 
-def _run(cmd, what):
-    with _HIPCC_SLOTS:
+_HIPCC_SLOTS = _PrioritySlots(max(1, (os.cpu_count() or 2)))
+# relative compile cost of the translation units (measured, 30-body robot), scaled by n^2 per robot
+_TU_COST = {"GRAD_F64": 208, "PASS_F32": 140, "PASS_F64": 125, "GRAD_F32": 114, "MINV_F64": 79, "MINV_F32": 74,
+            "RNEA_F64": 50, "RNEA_F32": 47, "FD_F32": 45, "FD_F64": 39, "COMMON": 3}
+
+
+def _run(cmd, what, cost: float = 0.0):
+    _HIPCC_SLOTS.acquire(cost)
+    try:
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=BUILD_DIR)
+    finally:
+        _HIPCC_SLOTS.release()
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed ({what}):\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     return r
@@ -104,7 +135,8 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
         # recompiles the units that include it (the optimiser, not the front end, is the cost).
         import hashlib
         base = [hipcc_path(), *[f for f in flags if f != "-shared"], "-DRBD_TU_SPLIT=1", f"-DRBD_TU_{tu}=1", "-include", hdr]
-        pre = _run([*base, "-E", "-P", src, "-o", "-"], f"{m.name} {tu} (preprocess)")
+        cost = _TU_COST.get(tu, 50) * m.n * m.n
+        pre = _run([*base, "-E", "-P", src, "-o", "-"], f"{m.name} {tu} (preprocess)", cost + 1e9)   # cheap: first
         key = hashlib.sha256((pre.stdout + "\0" + " ".join(flags)).encode()).hexdigest()[:32]
         obj = os.path.join(cache_dir, f"{key}.o")
         if os.path.exists(obj) and not force:
@@ -112,10 +144,13 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
         cmd = [*base, "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        t0 = time.time()
-        r = _run(cmd, f"{m.name} {tu}")
-        if os.environ.get("RBD_BUILD_TIMES"):
-            print(f"[build] {m.name:24s} {tu:9s} {time.time() - t0:7.1f} s", file=sys.stderr)
+        if os.environ.get("RBD_BUILD_TIMES"):     # CPU seconds of this unit (children of this thread's call)
+            t0 = time.time()
+            r = _run(["/bin/bash", "-c", 'TIMEFORMAT="%U %S"; time "$@"', "sh", *cmd], f"{m.name} {tu}", cost)
+            cpu = r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "?"
+            print(f"[build] {m.name:24s} {tu:9s} wall {time.time() - t0:7.1f} s  cpu(user sys) {cpu}", file=sys.stderr)
+        else:
+            r = _run(cmd, f"{m.name} {tu}", cost)
         if verbose and r.stderr:
             print(r.stderr, file=sys.stderr)
         os.replace(obj + f".{os.getpid()}.tmp", obj)
@@ -124,7 +159,7 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
     with ThreadPoolExecutor(max_workers=len(TRANSLATION_UNITS)) as ex:
         objs = list(ex.map(compile_tu, TRANSLATION_UNITS))
     _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out + ".tmp"],
-         f"{m.name} link")
+         f"{m.name} link", 2e9)
     os.replace(out + ".tmp", out)
     with open(stamp, "w") as f:
         f.write(digest + "\n")
