@@ -180,6 +180,9 @@ def main():
     # Clock ramp (untimed, before the W warm-up steps): from idle the GPU needs ~25 ms of sustained
     # load to reach its working clock -- with only 10 warm-up launches (3 ms) the timed launches
     # measured 287 us instead of 243 us on the same box.
+    if dist is not None:
+        dist.barrier()                       # builds the RCCL communicator (100s of ms): before the clock ramp
+        torch.cuda.synchronize()
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.3:
         for _ in range(20):
@@ -198,10 +201,10 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0          # this rank's K steps, device-synchronised; MAX over ranks below
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
         t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
