@@ -720,6 +720,10 @@ constexpr bool GRAD_USE_IDSVA = GRAD_IDSVA_OK;
 // world-frame kernel (rbd_idsva_tree.h) in fp32; every eligible robot can be forced onto it with
 // RBD_GRAD_KERNEL=tree (tests, experiments), and back with RBD_GRAD_KERNEL=column.
 constexpr bool GRAD_TREE_DEFAULT = GRAD_TREE_OK && !GRAD_USE_IDSVA && !GRAD_ACC_IN_REGS;
+// The one-lane chain kernel is an fp32 kernel: in fp64 its 18 n live world-frame values need more than
+// 512 VGPRs (94 spills at n = 7) and the two-lane column kernel is 6 % faster (iiwa, B = 262 144).
+template <class T>
+constexpr bool grad_chain_kernel() { return GRAD_USE_IDSVA && sizeof(T) == 4; }
 #endif  // RBD_NEED_GRAD
 
 // ---------------------------------------------------------------------------------------------
@@ -1226,7 +1230,7 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
   }
   if constexpr (TREE_ONLY) {
     return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: no kernel");   // unreachable (static_assert above)
-  } else if constexpr (GRAD_USE_IDSVA) {
+  } else if constexpr (grad_chain_kernel<T>()) {
     // one lane per configuration (rbd_idsva.h)
     const int64_t blocks = (B + 63) / 64;
     if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
@@ -1396,7 +1400,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   if (rc != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
-  if constexpr (GRAD_USE_IDSVA && grad_max_rows() == N) {
+  if constexpr (grad_chain_kernel<T>() && grad_max_rows() == N) {
     const int64_t blocks = (B + 63) / 64;
     if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
     const size_t lds = sizeof(T) * (size_t)64 * GRAD_TS;
