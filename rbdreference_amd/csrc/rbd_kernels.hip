@@ -136,6 +136,7 @@ template <class T>
 constexpr bool rnea_two_tiles() { return 2ull * 64 * odd_pad<6 * N>() * sizeof(T) <= 150 * 1024; }
 template <class T>
 constexpr size_t rnea_lds_bytes(bool vaf) {
+  if (!vaf && RNEA_PARK_VA && !rnea_two_tiles<T>()) return sizeof(T) * 64 * (size_t)odd_pad<6 * N>();   // f lives in LDS
   if (!vaf) return sizeof(T) * 64 * (size_t)odd_pad<N>();
   const size_t one = sizeof(T) * 64 * (size_t)odd_pad<6 * N>();
   return (RNEA_PARK_VA && rnea_two_tiles<T>()) ? 2 * one : one;
@@ -172,6 +173,10 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   constexpr bool PARK = WITH_VAF && RNEA_PARK_VA;
   constexpr bool TWO = rnea_two_tiles<T>();
+  // one tile only (fp64, big robots): f cannot stay in registers either (6 n doubles) -- it is
+  // recomputed into the tile once v and a have left, and the backward pass runs on the LDS rows
+  constexpr bool FLDS = RNEA_PARK_VA && !TWO;      // (c-only launches of such robots write f to the tile at once)
+  constexpr bool FLDS_C = FLDS && !WITH_VAF;
   T* ldsV = lds + lane * KP6;
   T* ldsA = lds + (TWO ? 64 * KP6 : 0) + lane * KP6;
   sfor<0, N>([&](auto J) {
@@ -188,7 +193,12 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
         ldsV[r * N + j] = v[j][r];
         if constexpr (TWO) ldsA[r * N + j] = a[j][r];
       });
-      pin6(f[j]);           // keep the bodies in program order (bounds the live v/a set)
+      // keep the bodies in program order (bounds the live v/a set)
+      if constexpr (FLDS) pin6(v[j]); else pin6(f[j]);
+    }
+    if constexpr (FLDS_C) {
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; ldsV[r * N + j] = f[j][r]; });
+      pin6(v[j]);
     }
   });
   if constexpr (PARK) {
@@ -213,6 +223,21 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
       });
       __syncthreads();
       flush_tile<K6>(lds, a_out + cfg0 * K6, lane, nvalid);
+      // third recursion: the local forces go into the (now idle) tile, lane-private rows
+      __syncthreads();
+      T v3[N][6], a3[N][6];
+      sfor<0, N>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int p = PARENT[j];
+        const JTrig<T> g{launder(tr[j].s), launder(tr[j].c)};
+        T xv[6], xa[6], f3[6];
+        if constexpr (p < 0)
+          rnea_fwd_body<j, HAS_QDD>(g, launder(qdv[j]), launder(qddv[j]), grav, zero6, zero6, xv, xa, v3[j], a3[j], f3);
+        else
+          rnea_fwd_body<j, HAS_QDD>(g, launder(qdv[j]), launder(qddv[j]), grav, v3[p], a3[p], xv, xa, v3[j], a3[j], f3);
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; ldsV[r * N + j] = f3[r]; });
+        pin6(v3[j]);
+      });
     }
   }
   // backward pass (:607-619)
@@ -222,11 +247,23 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
     sfor_down<0, N>([&](auto J) {
       constexpr int j = decltype(J)::value;
       constexpr int p = PARENT[j];
-      c[j] = S_dot<j>(f[j]);
-      if constexpr (p >= 0) {
-        T t[6];
-        xform_T<j>(tr[j], f[j], t);
-        sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+      if constexpr (FLDS) {
+        T fj[6];
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; fj[r] = ldsV[r * N + j]; });
+        c[j] = S_dot<j>(fj);
+        if constexpr (p >= 0) {
+          T t[6];
+          xform_T<j>(tr[j], fj, t);
+          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; ldsV[r * N + p] += t[r]; });
+        }
+        pin6(fj);
+      } else {
+        c[j] = S_dot<j>(f[j]);
+        if constexpr (p >= 0) {
+          T t[6];
+          xform_T<j>(tr[j], f[j], t);
+          sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+        }
       }
     });
   }
@@ -240,8 +277,13 @@ __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const
       sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = a[decltype(J)::value][decltype(R)::value]; }); });
       staged_store<K6>(lds, tmp, a_out + cfg0 * K6, lane, nvalid);
     }
-    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
-    staged_store<K6>(lds, tmp, f_out + cfg0 * K6, lane, nvalid);
+    if constexpr (FLDS) {
+      __syncthreads();
+      flush_tile<K6>(lds, f_out + cfg0 * K6, lane, nvalid);
+    } else {
+      sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
+      staged_store<K6>(lds, tmp, f_out + cfg0 * K6, lane, nvalid);
+    }
   }
   if (c_out != nullptr) staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
 }
