@@ -484,7 +484,7 @@ template <class T, bool HAS_QDD, bool FDG>
 __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_grad_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ qdd, T grav, int use_damping,
                                                        long long B, T* __restrict__ c_out,
-                                                       T* __restrict__ dcdu, const T* __restrict__ minv_in) {
+                                                       T* __restrict__ dcdu, const T* __restrict__ minv_in, int split) {
   static_assert(!FDG || GRAD_ACC_IN_REGS, "fused -Minv epilogue needs register accumulators");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
@@ -493,7 +493,11 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   const bool isqd = (lane & 1) != 0;
   constexpr int CFGS = grad_cfgs<T>();
   constexpr int NT = 2 * CFGS;
-  const long long cfg0 = (long long)blockIdx.x * CFGS;
+  // split == 1: every group of the robot in this block, one after the other; split == number of
+  // groups: the block handles group blockIdx.x % split of configurations blockIdx.x / split (the
+  // group is the FAST index, so that the blocks that write neighbouring rows of a configuration run
+  // close in time and L2 can merge their partial cache lines)
+  const long long cfg0 = (long long)(blockIdx.x / split) * CFGS;
   const long long rem = B - cfg0;
   const int nvalid = rem < CFGS ? (int)rem : CFGS;
   const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
@@ -531,9 +535,14 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
       }
     });
   };
+  // split > 1: one block per (configurations, group) -- the groups are independent problems, so
+  // giving each its own blocks multiplies the wave count and divides a wave's serial length
+  const int gsel = split > 1 ? (int)(blockIdx.x % split) : -1;
   sfor<0, N>([&](auto Rt) {
    constexpr int rt = decltype(Rt)::value;
    if constexpr (grp_head(rt)) {
+   constexpr int gi = grp_index(rt);
+   if (gsel < 0 || gsel == gi) {
    constexpr int row0 = grp_row0(rt);
    constexpr int rows = grp_rows(rt);
    T* my = tile + slot * GRAD_TS + (isqd ? N : 0) - row0 * GRAD_ROW;   // my[i * 2N + c], rows of this group
@@ -541,13 +550,15 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   // range-reduction branch would otherwise fence each load behind the previous joint's trig: n
   // serialized HBM round trips); the NEXT group's loads are issued before this group's passes, so
   // their latency hides behind a whole group of arithmetic.
-  if constexpr (rt == grp_first()) load_group(Rt);
+  if (gsel >= 0 || rt == grp_first()) load_group(Rt);
 #ifdef RBD_EXP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   RBD_STAMP(1);
   pair_trig<rt, 0>(isqd, qv, tr);
-  if constexpr (grp_next(rt) >= 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
+  if constexpr (grp_next(rt) >= 0) {
+    if (gsel < 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
+  }
   RBD_STAMP(2);
 
   // ---- pass 1: RNEA forward + backward -> c and the ACCUMULATED forces f (:569-619) -----------
@@ -745,6 +756,7 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     }
   }
   if constexpr (GRAD_PER_ROOT && rows != N) __syncthreads();   // the next group reuses the tile
+   }  // this block's group
    }  // grp_head(rt)
   });
 }
@@ -1232,8 +1244,12 @@ int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_
   auto k = rnea_grad_kernel<T, HAS_QDD, FDG>;
   int rc;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(2 * CFGS), lds, (hipStream_t)stream, q, qd, qdd, gravity,
-                     use_damping, (long long)B, c, dc_du, minv_in);
+  // independent root subtrees get their own blocks (not with the fused -Minv epilogue, whose Minv
+  // tile is shared by the groups)
+  const int split = (!FDG && GRAD_PER_ROOT && n_groups() > 1) ? n_groups() : 1;
+  if (blocks * split > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+  hipLaunchKernelGGL(k, dim3((unsigned)(blocks * split)), dim3(2 * CFGS), lds, (hipStream_t)stream, q, qd, qdd, gravity,
+                     use_damping, (long long)B, c, dc_du, minv_in, split);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
   return 0;
