@@ -148,3 +148,28 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "/root/reference" not in txt or f.endswith((".py", ".hip", ".h")), f
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="needs the ROCm LLVM tools")
+def test_fp32_kernels_of_built_libraries_do_not_spill():
+    """DESIGN.md §5 claims every fp32 kernel of every test robot is spill-free (spills are HBM
+    traffic, §3).  Checked on whatever per-robot libraries are present (build() makes all seven);
+    reads the code-object metadata only, no GPU."""
+    import glob
+    import subprocess
+    import sys
+    libs = sorted(glob.glob(os.path.join(ROOT, "rbdreference_amd", "_build", "librbd_*_*.so")))
+    libs = [l for l in libs if l.count(".") == 1]            # skip tagged experiment builds
+    if not libs:
+        pytest.skip("no per-robot library built yet")
+    bad = []
+    for lib in libs:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), lib],
+                             capture_output=True, text=True, check=True).stdout
+        for line in out.splitlines():
+            name = line.split("vgpr=")[0].strip()
+            spill = int(line.rsplit("spill=", 1)[1])
+            scratch = int(line.split("scratch=")[1].split()[0])
+            if "<float" in name and (spill or scratch):
+                bad.append((os.path.basename(lib), name, spill, scratch))
+    assert not bad, bad
