@@ -141,6 +141,15 @@ RBD_DEV void sym_apply(const SymB<T>& S, const T (&x)[6], T (&y)[6]) {
   y[3] = -ga[0]; y[4] = -ga[1]; y[5] = -ga[2];
 }
 
+// The block is ONE wave and a wave's LDS operations execute in order: ordering LDS traffic between
+// lanes needs a compiler-level fence only.  __syncthreads() would add s_waitcnt vmcnt(0), i.e. wait
+// for every global store / load still in flight.
+#ifdef RBD_EXP_BLOCKSYNC
+#define IDS_WAVE_SYNC() __syncthreads()
+#else
+#define IDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // rnea_grad, one configuration per lane (64 per block).  Same signature and output layout as
 // rnea_grad_kernel<T, HAS_QDD, false>.
@@ -478,18 +487,18 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     if constexpr (FDG) {
       T D[GRAD_TILE];
       sfor<0, GRAD_TILE>([&](auto K_) { constexpr int k = decltype(K_)::value; D[k] = my[k]; });
-      __syncthreads();                                   // every lane has its row in registers
+      IDS_WAVE_SYNC();                                   // every lane has its row in registers
       {
         const T* msrc = minv_in + cfg0 * (N * N);
         for (int g = lane; g < nvalid * N * N; g += CFGS) tile[g] = msrc[g];
       }
-      __syncthreads();
+      IDS_WAVE_SYNC();
       T Mm[N * N];
       {
         const T* mrow = tile + (lane < nvalid ? lane : 0) * (N * N);
         sfor<0, N * N>([&](auto K_) { constexpr int k = decltype(K_)::value; Mm[k] = mrow[k]; });
       }
-      __syncthreads();                                   // Minv is in registers; the tile can take the outputs
+      IDS_WAVE_SYNC();                                   // Minv is in registers; the tile can take the outputs
       sfor<0, N>([&](auto I_) {
         sfor<0, 2 * N>([&](auto C_) {
           constexpr int i = decltype(I_)::value, c = decltype(C_)::value;
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     }
     // ---- stream this group's rows out ---------------------------------------------------------------
     IDS_STAMP(4);
-    __syncthreads();
+    IDS_WAVE_SYNC();
     {
       constexpr int RW = rows * GRAD_ROW;
       T* gdst = dcdu + cfg0 * GRAD_TILE + row0 * GRAD_ROW;
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
         }
       }
     }
-    if constexpr (rows != N) __syncthreads();
+    if constexpr (rows != N) IDS_WAVE_SYNC();
 #ifdef RBD_EXP_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     IDS_STAMP(5);
