@@ -485,13 +485,23 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     });
 
     if constexpr (FDG) {
+      // the block's Minv rows: n^2 coalesced loads per lane, all issued before anything waits on them
+      // (as a run-time loop of load -> ds_write pairs this staging paid one memory round trip per
+      // iteration)
+      T ms[N * N];
+      {
+        const T* msrc = minv_in + cfg0 * (N * N);
+        const int lim = nvalid * N * N;
+        sfor<0, N * N>([&](auto K_) {
+          constexpr int k = decltype(K_)::value;
+          const int g = lane + CFGS * k;
+          ms[k] = msrc[g < lim ? g : 0];
+        });
+      }
       T D[GRAD_TILE];
       sfor<0, GRAD_TILE>([&](auto K_) { constexpr int k = decltype(K_)::value; D[k] = my[k]; });
       IDS_WAVE_SYNC();                                   // every lane has its row in registers
-      {
-        const T* msrc = minv_in + cfg0 * (N * N);
-        for (int g = lane; g < nvalid * N * N; g += CFGS) tile[g] = msrc[g];
-      }
+      sfor<0, N * N>([&](auto K_) { constexpr int k = decltype(K_)::value; tile[lane + CFGS * k] = ms[k]; });
       IDS_WAVE_SYNC();
       T Mm[N * N];
       {
