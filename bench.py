@@ -8,11 +8,15 @@
 One *step* = one pass of the hot path over one batch: a single ``rbd_rnea_grad_f32`` launch that
 maps ``B`` rows ``(q, qd, qdd)`` (already resident in HBM) to ``(c, dc_du)`` -- the work of ``B``
 calls of the reference's ``rnea_grad`` (``/root/reference/RBDReference.py:1345-1368``).  Workload:
-BASELINE.json configs[3] ("7-DoF iiwa rnea_grad batch=1M", the configuration the metric's
-1/2/4/8-GPU series is quoted on); the full 1 048 576-row batch fits one MI355X, so every rank
-evaluates its own 1 048 576 rows (weak scaling, no data-path collective: rows are independent,
-SURVEY.md §8e).  configs[1] (B = 4096) is reported beside it under "extra" -- at that size a
-launch is latency-bound and says nothing about the roofline.
+BASELINE.json configs[3] ("7-DoF iiwa rnea_grad batch=1M sharded across 8xMI355X"): a GLOBAL batch of
+``--batch`` (1 048 576) rows, rank r evaluating rows ``shard_bounds(B, world, r)`` -- strong scaling,
+the configuration as written, no data-path collective (rows are independent).  With
+``--scaling weak`` every rank evaluates its own ``--batch`` rows instead.  Under torchrun the other mode
+is measured in the same run and reported as a second object (``"weak"`` / ``"strong"``); at N = 1 the
+two coincide.  Every step uses the next of ``--rotate`` (default 4) input/output buffer sets, so
+that more input bytes are in flight (4 x 88 MB) than the 256 MB Infinity Cache holds.  configs[1]
+(B = 4096) is reported beside it under "extra" -- at that size a launch is latency-bound and says
+nothing about the roofline.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
 ``roofline`` (algorithmic HBM bytes per launch / measured kernel time vs the 8 TB/s peak; the
@@ -43,7 +47,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="rows per GPU per step")
+    ap.add_argument("--batch", type=int, default=1 << 20,
+                    help="rows per step: the global batch (strong scaling) / rows per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--rotate", type=int, default=4, help="input/output buffer sets cycled through by the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
@@ -51,7 +58,7 @@ def parse():
 
 def make_inputs(B, n, seed, device, dtype=torch.float32):
     """Synthetic inputs of SURVEY.md §8d: q ~ U(-pi, pi), qd, qdd ~ U(-1, 1); numpy PCG64 on the
-    host, uploaded before the timed region."""
+    host, uploaded before the timed region (device "cpu": left on the host)."""
     rng = np.random.default_rng(seed)
     q = rng.uniform(-np.pi, np.pi, (B, n)).astype(np.float32 if dtype == torch.float32 else np.float64)
     qd = rng.uniform(-1, 1, (B, n)).astype(q.dtype)
@@ -60,20 +67,31 @@ def make_inputs(B, n, seed, device, dtype=torch.float32):
 
 
 class GradStep:
-    """Pre-allocated buffers + a direct C-ABI launch on torch's current stream."""
+    """Pre-allocated buffers + a direct C-ABI launch on torch's current stream.  `sets` input/output
+    buffer sets are used round-robin (each call takes the next one)."""
 
-    def __init__(self, rbd, q, qd, qdd):
-        self.rbd, self.q, self.qd, self.qdd = rbd, q, qd, qdd
+    def __init__(self, rbd, inputs):
+        self.rbd = rbd
+        self.inputs = inputs                      # list of (q, qd, qdd)
+        q = inputs[0][0]
         B, n = q.shape
         self.B = B
-        self.c = torch.empty((B, n), device=q.device, dtype=q.dtype)
-        self.dc = torch.empty((B, n, 2 * n), device=q.device, dtype=q.dtype)
+        self.outs = [(torch.empty((B, n), device=q.device, dtype=q.dtype),
+                      torch.empty((B, n, 2 * n), device=q.device, dtype=q.dtype)) for _ in inputs]
         self.fn = rbd._fn("rbd_rnea_grad", q.dtype)
         self.stream = torch.cuda.current_stream(q.device).cuda_stream
+        self.args = [(a.data_ptr(), b.data_ptr(), c_.data_ptr(), -9.81, 0, B, o[0].data_ptr(), o[1].data_ptr(), self.stream)
+                     for (a, b, c_), o in zip(inputs, self.outs)]
+        self.k = 0
+
+    @property
+    def dc(self):
+        return self.outs[0][1]
 
     def __call__(self):
-        rc = self.fn(self.q.data_ptr(), self.qd.data_ptr(), self.qdd.data_ptr(), -9.81, 0, self.B,
-                     self.c.data_ptr(), self.dc.data_ptr(), self.stream)
+        a = self.args[self.k]
+        self.k = (self.k + 1) % len(self.args)
+        rc = self.fn(*a)
         if rc != 0:
             self.rbd._lib.check(rc)
 
@@ -152,6 +170,46 @@ def cpu_baseline(robot, seed, budget_s=15.0):
     return main
 
 
+def sources_digest():
+    """sha256 over the kernel sources + C-ABI header: profiles/hbm_traffic.json is only attached to a
+    bench line produced by the same code."""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "rbdreference_amd", "csrc")
+    for f in sorted(os.listdir(cs)):
+        h.update(f.encode()); h.update(open(os.path.join(cs, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "rbd_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def timed_steps(step, steps, warmup, dist, dev):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.
+    Returns (wall seconds, HIP-event ms per step on the launch stream): this rank's."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0          # this rank's K steps, device-synchronised; MAX over ranks below
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kern_ms = ev0.elapsed_time(ev1) / steps
+    if dist is not None:
+        t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kern_ms = t[0].item(), t[1].item()
+    return wall, kern_ms
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,11 +229,28 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from rbdreference_amd import RBDReference, iiwa_like
+    from rbdreference_amd._lib import RBD_OP_RNEA_GRAD
+    from rbdreference_amd.dist import shard_bounds
     robot = iiwa_like()
     rbd = RBDReference(robot, build=False)     # prebuilt by __graft_entry__.build(); raises if missing
     B = args.batch
-    q, qd, qdd = make_inputs(B, N_DOF, 3 + rank, dev)
-    step = GradStep(rbd, q, qd, qdd)
+    nsets = max(1, args.rotate)
+
+    def make_step(mode):
+        """strong: this rank's rows of the GLOBAL batch (seed per set, identical on every rank, sliced
+        with shard_bounds); weak: `B` rows of this rank's own."""
+        sets = []
+        for k in range(nsets):
+            if mode == "strong":
+                a, b = shard_bounds(B, world, rank)
+                full = make_inputs(B, N_DOF, 3 + 17 * k, "cpu")
+                sets.append(tuple(x[a:b].contiguous().to(dev) for x in full))
+            else:
+                sets.append(make_inputs(B, N_DOF, 3 + 17 * k + 1000 * rank, dev))
+        return GradStep(rbd, sets)
+
+    step = make_step(args.scaling)
+    rows_rank = step.B
 
     # Clock ramp (untimed, before the W warm-up steps): from idle the GPU needs ~25 ms of sustained
     # load to reach its working clock -- with only 10 warm-up launches (3 ms) the timed launches
@@ -188,35 +263,25 @@ def main():
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0          # this rank's K steps, device-synchronised; MAX over ranks below
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-    if dist is not None:
-        t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kern_ms = t[0].item(), t[1].item()
+    wall, kern_ms = timed_steps(step, args.steps, args.warmup, dist, dev)
 
-    # parity spot-check of what was just timed (first 256 rows vs the fp64 oracle), rank 0
+    other = None
+    if world > 1:                            # the other scaling mode, same run, reported beside the headline
+        omode = "weak" if args.scaling == "strong" else "strong"
+        ostep = make_step(omode)
+        ow, ok = timed_steps(ostep, args.steps, args.warmup, dist, dev)
+        orows = B if omode == "strong" else world * B
+        other = {"scaling": omode, "value": orows * args.steps / ow, "unit": "evals/s", "ms_per_step": ow / args.steps * 1e3,
+                 "kernel_ms": ok, "rows_per_gpu": ostep.B, "global_batch": orows}
+        del ostep
+
+    # parity spot-check of what was just timed (first 256 rows of buffer set 0 vs the fp64 oracle), rank 0
     parity = None
     if rank == 0:
         from oracle import rbd_oracle as orc
         om = orc.model_from_robot(robot)
-        k = min(256, B)
+        k = min(256, rows_rank)
+        q, qd, qdd = step.inputs[0]
         c_ref, dc_ref = orc.rnea_grad(om, q[:k].double().cpu().numpy(), qd[:k].double().cpu().numpy(),
                                       qdd[:k].double().cpu().numpy(), return_c=True)
         got = step.dc[:k].double().cpu().numpy().reshape(k, -1)
@@ -224,61 +289,99 @@ def main():
         parity = float(np.max(np.max(np.abs(got - ref), 1) / np.max(np.abs(ref), 1)))
 
     if rank == 0:
-        evals = world * B * args.steps
+        rows_global = B if args.scaling == "strong" else world * B
+        evals = rows_global * args.steps
         value = evals / wall
-        achieved = BYTES_PER_EVAL * B / (kern_ms * 1e-3) / 1e9
+        achieved = BYTES_PER_EVAL * rows_rank / (kern_ms * 1e-3) / 1e9       # one launch of the slowest rank
+        kernel = rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, rows_rank)
+        digest = sources_digest()
         traffic = None
+        traffic_note = "no profiles/hbm_traffic.json for this kernel / batch / source digest"
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("batch") == B:
+                if tj.get("batch") == rows_rank and tj.get("kernel") == kernel and tj.get("sources_digest") == digest:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    valu = tj.get("valu")
+                    traffic_note = tj.get("note")
             except Exception:
                 traffic = None
         out = {
             "metric": "batched RNEA+grad evals/s (7-DoF)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: 7-DoF iiwa-like rnea_grad (c + dc_du), fp32, "
-                                   f"B={B} rows per GPU per step, batch-sharded (weak), inputs resident in HBM",
-                       "robot": "iiwa_like", "batch_per_gpu": B, "global_batch": world * B,
+                                   f"global batch {rows_global} rows per step, {rows_rank} rows per GPU "
+                                   f"({args.scaling} scaling, batch-sharded), inputs resident in HBM, "
+                                   f"{nsets} buffer sets rotated",
+                       "robot": "iiwa_like", "batch_per_gpu": rows_rank, "global_batch": rows_global,
+                       "buffer_sets": nsets,
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_eval": BYTES_PER_EVAL, "kernel": "rnea_grad_idsva_kernel<float,true,false>",
-                         "kernel_ms": kern_ms,
-                         "note": "kernel is FP32-VALU-bound (SURVEY.md §8d); HBM fraction from algorithmic bytes"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_eval": BYTES_PER_EVAL, "kernel": kernel,
+                         "kernel_ms": kern_ms, "sources_digest": digest, "valu": valu,
+                         "note": "HBM fraction from algorithmic bytes (SURVEY.md §8d: 504 B per evaluation); the "
+                                 "kernel's arithmetic (~4.8 k VALU wave-instructions per 64 evaluations) puts its "
+                                 "FP32-VALU floor at ~0.55 of this launch time, see `valu` when a matching SQ "
+                                 "profile is committed"},
             "parity_max_rel_err_first_256_rows": parity,
         }
+        if other is not None:
+            out[other["scaling"]] = other
+        q, qd, qdd = step.inputs[0]
         if not args.no_extra and world == 1:
             extra = {}
             # BASELINE configs[1]: B = 4096, rnea + rnea_grad back to back
             q4, qd4, qdd4 = make_inputs(4096, N_DOF, 1, dev)
-            s4 = GradStep(rbd, q4, qd4, qdd4)
+            s4 = GradStep(rbd, [(q4, qd4, qdd4)])
             ms = time_extra_ms(s4, 200, 20)
             extra["cfg1_iiwa_rnea_grad_B4096_f32"] = {"ms_per_launch": ms, "evals_per_s": 4096 / (ms * 1e-3)}
             ms = time_extra_ms(lambda: rbd.rnea(q4, qd4, qdd4), 100, 10)
             extra["cfg1_iiwa_rnea_cvaf_B4096_f32_api"] = {"ms_per_call": ms, "evals_per_s": 4096 / (ms * 1e-3)}
+            Bq = q.shape[0]
             ms = time_extra_ms(lambda: rbd.minv(q), 10, 2)
-            extra["iiwa_minv_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3),
-                                                   "alg_GBps": B * (7 + 49) * 4 / (ms * 1e-3) / 1e9}
+            extra["iiwa_minv_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
+                                                    "alg_GBps": Bq * (7 + 49) * 4 / (ms * 1e-3) / 1e9}
             ms = time_extra_ms(lambda: rbd.rnea(q, qd, qdd), 10, 2)
-            extra["iiwa_rnea_cvaf_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3),
-                                                        "alg_GBps": B * 22 * 7 * 4 / (ms * 1e-3) / 1e9}
+            extra["iiwa_rnea_cvaf_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
+                                                         "alg_GBps": Bq * 22 * 7 * 4 / (ms * 1e-3) / 1e9}
             ms = time_extra_ms(lambda: rbd.aba(q, qd, qdd), 10, 2)
-            extra["iiwa_aba_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3),
-                                                  "alg_GBps": B * 4 * 7 * 4 / (ms * 1e-3) / 1e9}
+            extra["iiwa_aba_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
+                                                   "alg_GBps": Bq * 4 * 7 * 4 / (ms * 1e-3) / 1e9}
             ms = time_extra_ms(lambda: rbd.forward_dynamics_grad(q, qd, qdd), 10, 2)
-            extra["iiwa_forward_dynamics_grad_B%d_f32_api" % B] = {"ms_per_call": ms, "evals_per_s": B / (ms * 1e-3)}
+            extra["iiwa_forward_dynamics_grad_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3)}
+            try:
+                # the same kernel on a 7-chain with DENSE joint frames and inertias (random_chain_n7): what
+                # the iiwa-like robot's structural zeros / unit entries are worth
+                from __graft_entry__ import test_robots
+                rc7 = RBDReference([r for r in test_robots() if r.name == "random_chain_n7"][0], build=False)
+                sd = GradStep(rc7, [(q, qd, qdd)])
+                ms = time_extra_ms(sd, 10, 2)
+                extra["dense_random_chain_n7_rnea_grad_B%d_f32" % Bq] = {
+                    "ms_per_launch": ms, "evals_per_s": Bq / (ms * 1e-3), "alg_GBps": Bq * BYTES_PER_EVAL / (ms * 1e-3) / 1e9,
+                    "kernel": rc7._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, Bq)}
+                del sd
+            except Exception as e:
+                extra["dense_chain_error"] = repr(e)
             try:
                 from rbdreference_amd import atlas_like, quadruped_like
-                ra = RBDReference(atlas_like(), build=False)
+                atlas = atlas_like()
+                ra = RBDReference(atlas, build=False)
                 qa, qda, qdda = make_inputs(16384, 30, 2, dev)
                 ms = time_extra_ms(lambda: ra.minv(qa), 20, 3)
                 extra["cfg2_atlas_minv_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
                                                        "alg_GBps": 16384 * 3720 / (ms * 1e-3) / 1e9}
+                # measured parity of that launch (the error itself, not only a pass/fail)
+                from oracle import rbd_oracle as orc
+                oma = orc.model_from_robot(atlas)
+                Mi = ra.minv(qa[:256]).double().cpu().numpy().reshape(256, -1)
+                Mr = orc.minv(oma, qa[:256].double().cpu().numpy()).reshape(256, -1)
+                extra["cfg2_atlas_minv_B16384_f32"]["max_rel_err_first_256_rows"] = float(
+                    np.max(np.max(np.abs(Mi - Mr), 1) / np.max(np.abs(Mr), 1)))
                 ms = time_extra_ms(lambda: ra.rnea(qa, qda, qdda), 20, 3)
                 extra["cfg2_atlas_rnea_cvaf_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
                                                             "alg_GBps": 16384 * 2640 / (ms * 1e-3) / 1e9}

@@ -49,6 +49,31 @@ const char* rbd_last_error(void);
 /* The robot this library was compiled for (host-side, no GPU needed). */
 int rbd_model_info(rbd_model_info_t* out);
 
+/* Kernel selection.  Several kernels may serve one entry point; which one runs is
+ * decided per robot at compile time and per launch from B.  rbd_set_option overrides the choice
+ * where the override is built into the library (tests run every kernel of every robot this way;
+ * a value the library cannot honour is ignored).  Options only ever select between kernels that
+ * compute the same result.  Process-wide, thread-safe, no environment variables are read.
+ *   RBD_OPT_GRAD_KERNEL    rbd_rnea_grad: AUTO | TREE (chain-by-chain world-frame kernel)
+ *   RBD_OPT_MINV_PHASE_A   rbd_minv, two-phase robots: AUTO | LANE (one lane per configuration) |
+ *                          IA8 (eight lanes per configuration)
+ * rbd_kernel_name writes the name of the kernel (the dominant one of a multi-launch entry point) that
+ * `op` would launch for a batch of B rows of elem_size-byte scalars under the current options. */
+#define RBD_OPT_GRAD_KERNEL 0
+#define RBD_OPT_MINV_PHASE_A 1
+#define RBD_OPT_COUNT_ 2
+#define RBD_GRAD_KERNEL_AUTO 0
+#define RBD_GRAD_KERNEL_TREE 1
+#define RBD_MINV_PHASE_A_AUTO 0
+#define RBD_MINV_PHASE_A_LANE 1
+#define RBD_MINV_PHASE_A_IA8 2
+#define RBD_OP_RNEA 0
+#define RBD_OP_RNEA_GRAD 1
+#define RBD_OP_MINV 2
+int rbd_set_option(int option, int value);
+int rbd_get_option(int option);
+int rbd_kernel_name(int op, int elem_size, int64_t B, char* buf, size_t len);
+
 /* RBDReference.rnea(q, qd, qdd=None, GRAVITY)            (RBDReference.py:623-628)
  *   q, qd, qdd : [B, n]   (qdd may be NULL == the reference's qdd=None, :589)
  *   c          : [B, n]

@@ -15,10 +15,16 @@ from .packer import ABI_VERSION, PackedModel
 
 RBD_MAX_BODIES = 64
 RBD_ERR_ARG, RBD_ERR_UNSUPPORTED, RBD_ERR_WORKSPACE = -1, -2, -3
+# rbd_set_option / rbd_kernel_name constants (include/rbd_hip.h)
+RBD_OPT_GRAD_KERNEL, RBD_OPT_MINV_PHASE_A = 0, 1
+RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_TREE = 0, 1
+RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8 = 0, 1, 2
+RBD_OP_RNEA, RBD_OP_RNEA_GRAD, RBD_OP_MINV = 0, 1, 2
 
 # every symbol include/rbd_hip.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
     "rbd_abi_version", "rbd_last_error", "rbd_model_info",
+    "rbd_set_option", "rbd_get_option", "rbd_kernel_name",
     "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
     "rbd_rnea_fpass_f32", "rbd_rnea_fpass_f64", "rbd_rnea_bpass_f32", "rbd_rnea_bpass_f64",
     "rbd_minv_workspace_bytes", "rbd_minv_f32", "rbd_minv_f64",
@@ -54,6 +60,12 @@ def _declare(lib):
     lib.rbd_last_error.argtypes = []
     lib.rbd_model_info.restype = c_int
     lib.rbd_model_info.argtypes = [POINTER(RbdModelInfo)]
+    lib.rbd_set_option.restype = c_int
+    lib.rbd_set_option.argtypes = [c_int, c_int]
+    lib.rbd_get_option.restype = c_int
+    lib.rbd_get_option.argtypes = [c_int]
+    lib.rbd_kernel_name.restype = c_int
+    lib.rbd_kernel_name.argtypes = [c_int, c_int, c_int64, c_char_p, c_size_t]
     for sfx, ft in (("f32", c_float), ("f64", c_double)):
         f = getattr(lib, f"rbd_rnea_{sfx}")
         f.restype = c_int
@@ -124,3 +136,15 @@ class RbdLibrary:
     def check(self, rc: int):
         if rc != 0:
             raise RbdError(rc, (self.lib.rbd_last_error() or b"").decode())
+
+    def set_option(self, option: int, value: int) -> None:
+        self.check(self.lib.rbd_set_option(option, value))
+
+    def get_option(self, option: int) -> int:
+        return int(self.lib.rbd_get_option(option))
+
+    def kernel_name(self, op: int, elem_size: int, B: int) -> str:
+        """Name of the (dominant) kernel entry point `op` launches for B rows (host-side, no GPU)."""
+        buf = ctypes.create_string_buffer(128)
+        self.check(self.lib.rbd_kernel_name(op, elem_size, B, buf, len(buf)))
+        return buf.value.decode()

@@ -15,7 +15,7 @@ import threading
 import time
 from typing import Optional
 
-from .packer import PackedModel, emit_header, pack_robot
+from .packer import PackedModel, emit_header, pack_robot, safe_name
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -39,8 +39,7 @@ def hipcc_path() -> str:
 
 
 def lib_path(m: PackedModel) -> str:
-    safe = "".join(ch if ch.isalnum() or ch == "_" else "_" for ch in m.name)
-    return os.path.join(BUILD_DIR, f"librbd_{safe}_{m.hash}.so")
+    return os.path.join(BUILD_DIR, f"librbd_{safe_name(m.name)}_{m.hash}.so")
 
 
 def header_path(m: PackedModel) -> str:
@@ -108,10 +107,44 @@ def _run(cmd, what, cost: float = 0.0):
     return r
 
 
+class _BuildLock:
+    """Inter-process lock around check -> build -> publish of one library (``flock`` on
+    ``<lib>.lock``).  One process per GPU means every rank may construct ``RBDReference(robot)`` at
+    the same moment: the first one builds, the others block here and then find the finished library."""
+
+    def __init__(self, path: str):
+        self.path = path + ".lock"
+        self.fh = None
+
+    def __enter__(self):
+        import fcntl
+        self.fh = open(self.path, "w")
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
+        return False
+
+
+def _up_to_date(out: str, digest: str) -> bool:
+    stamp = out + ".stamp"
+    try:
+        with open(stamp) as f:
+            return os.path.exists(out) and f.read().strip() == digest
+    except OSError:
+        return False
+
+
 def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
                 extra_flags: Optional[list] = None, tag: str = "") -> str:
     """Compile the library for packed model `m` (no-op when an up-to-date one exists).  The single
-    source file is compiled as several translation units in parallel (-DRBD_TU_*) and linked."""
+    source file is compiled as several translation units in parallel (-DRBD_TU_*) and linked.
+    Safe across processes: the whole check/build/publish sequence holds an exclusive file lock, and
+    every intermediate file (generated header, objects, link output) has a process-unique name and
+    is published with an atomic rename."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(BUILD_DIR, exist_ok=True)
     out = lib_path(m)
@@ -119,12 +152,22 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
         out = out[:-3] + f".{tag}.so"
     flags = list(HIPCC_FLAGS) + list(extra_flags or [])
     digest = _sources_digest(m, flags)
-    stamp = out + ".stamp"
-    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+    if not force and _up_to_date(out, digest):
         return out
+    with _BuildLock(out):
+        if not force and _up_to_date(out, digest):     # another process finished it while we waited
+            return out
+        return _build_locked(m, out, flags, digest, force, verbose)
+
+
+def _build_locked(m, out, flags, digest, force, verbose) -> str:
+    from concurrent.futures import ThreadPoolExecutor
+    uniq = f"{os.getpid()}.{threading.get_ident()}"
     hdr = header_path(m)
-    with open(hdr, "w") as f:
+    hdr_tmp = f"{hdr}.{uniq}.tmp"
+    with open(hdr_tmp, "w") as f:
         f.write(emit_header(m))
+    os.replace(hdr_tmp, hdr)                  # same content from every writer; rename is atomic
     src = os.path.join(CSRC, "rbd_kernels.hip")
 
     cache_dir = os.path.join(BUILD_DIR, "objcache")
@@ -141,7 +184,8 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
         obj = os.path.join(cache_dir, f"{key}.o")
         if os.path.exists(obj) and not force:
             return obj
-        cmd = [*base, "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
+        tmp = f"{obj}.{uniq}.{tu}.tmp"
+        cmd = [*base, "-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         if os.environ.get("RBD_BUILD_TIMES"):     # CPU seconds of this unit (children of this thread's call)
@@ -153,16 +197,19 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
             r = _run(cmd, f"{m.name} {tu}", cost)
         if verbose and r.stderr:
             print(r.stderr, file=sys.stderr)
-        os.replace(obj + f".{os.getpid()}.tmp", obj)
+        os.replace(tmp, obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(TRANSLATION_UNITS)) as ex:
         objs = list(ex.map(compile_tu, TRANSLATION_UNITS))
-    _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out + ".tmp"],
+    link_tmp = f"{out}.{uniq}.tmp"
+    _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", link_tmp],
          f"{m.name} link", 2e9)
-    os.replace(out + ".tmp", out)
-    with open(stamp, "w") as f:
+    os.replace(link_tmp, out)
+    stamp_tmp = f"{out}.stamp.{uniq}.tmp"
+    with open(stamp_tmp, "w") as f:
         f.write(digest + "\n")
+    os.replace(stamp_tmp, out + ".stamp")
     return out
 
 

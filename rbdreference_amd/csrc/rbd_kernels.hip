@@ -501,13 +501,6 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   const long long rem = B - cfg0;
   const int nvalid = rem < CFGS ? (int)rem : CFGS;
   const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
-#ifdef RBD_EXP_STAMPS
-#define RBD_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[k] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-  unsigned long long stamps[8];
-#else
-#define RBD_STAMP(k) do {} while (0)
-#endif
-  RBD_STAMP(0);
   T* mtile = tile + CFGS * GRAD_TS;      // FDG: [CFGS][N*N] copy of Minv
   if constexpr (FDG) {
     const T* msrc = minv_in + cfg0 * (N * N);
@@ -551,15 +544,10 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   // serialized HBM round trips); the NEXT group's loads are issued before this group's passes, so
   // their latency hides behind a whole group of arithmetic.
   if (gsel >= 0 || rt == grp_first()) load_group(Rt);
-#ifdef RBD_EXP_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  RBD_STAMP(1);
   pair_trig<rt, 0>(isqd, qv, tr);
   if constexpr (grp_next(rt) >= 0) {
     if (gsel < 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
   }
-  RBD_STAMP(2);
 
   // ---- pass 1: RNEA forward + backward -> c and the ACCUMULATED forces f (:569-619) -----------
   {
@@ -591,8 +579,6 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   if (c_out != nullptr && !isqd && slot < nvalid) {
     sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (grp_has(rt, j)) c_out[b * N + j] = c[j]; });
   }
-
-  RBD_STAMP(3);
   // ---- pass 2: forward gradient sweep (:1139-1185, :1210-1252 fused; backward passes folded in)
   // v, a are recomputed here from laundered inputs instead of being kept from pass 1.
   // Column slot s of body j = its ancestor-or-self at depth s.  dv/da[j][s] are this lane's
@@ -680,7 +666,6 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   });
 
   // ---- this group is complete: finish its rows in the LDS image and stream them out -----------
-  RBD_STAMP(4);
   if constexpr (FDG) {
     // out[i][c] = - sum_k Minv[i][k] dc[k][c]  (:1382-1383); Minv and dc are block-diagonal over groups
     __syncthreads();                       // mtile is complete (written by other lanes at the start)
@@ -723,13 +708,6 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     });
   }
   __syncthreads();
-  RBD_STAMP(5);
-#ifdef RBD_EXP_STAMPS
-  if (lane == 0 && c_out != nullptr) {   // DIAGNOSTIC BUILD ONLY: phase durations overwrite c of the block's first row
-    for (int k = 0; k < 5; ++k) c_out[cfg0 * N + k] = (T)(float)(stamps[k + 1] - stamps[k]);
-    c_out[cfg0 * N + 5] = (T)(float)(stamps[0] & 0xffffff);
-  }
-#endif
   {
     constexpr int RW = rows * GRAD_ROW;                         // elements of this group per configuration
     T* gdst = dcdu + cfg0 * GRAD_TILE + row0 * GRAD_ROW;
@@ -771,8 +749,8 @@ constexpr bool GRAD_USE_IDSVA = false;
 constexpr bool GRAD_USE_IDSVA = GRAD_IDSVA_OK;
 #endif
 // Trees whose column-recursion accumulators do not fit registers (Atlas) take the chain-by-chain
-// world-frame kernel (rbd_idsva_tree.h) in fp32; every eligible robot can be forced onto it with
-// RBD_GRAD_KERNEL=tree (tests, experiments), and back with RBD_GRAD_KERNEL=column.
+// world-frame kernel (rbd_idsva_tree.h) in fp32; every eligible robot can be put on it with
+// rbd_set_option(RBD_OPT_GRAD_KERNEL, RBD_GRAD_KERNEL_TREE) (tests, experiments).
 constexpr bool GRAD_TREE_DEFAULT = GRAD_TREE_OK && !GRAD_USE_IDSVA && !GRAD_ACC_IN_REGS;
 // The one-lane chain kernel is an fp32 kernel: in fp64 its 18 n live world-frame values need more than
 // 512 VGPRs (94 spills at n = 7) and the two-lane column kernel is 6 % faster (iiwa, B = 262 144).
@@ -1132,9 +1110,13 @@ constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
 // C-ABI (include/rbd_hip.h)
 // =============================================================================================
 #include "../../include/rbd_hip.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
+constexpr int RBD_MAX_DEVICES = 16;
 
 
 // thread-local message buffer behind rbd_last_error(); one instance, owned by the COMMON unit
@@ -1146,6 +1128,17 @@ extern "C" char* rbd_err_buf(void) {
 }
 #endif
 constexpr size_t RBD_ERR_LEN = 512;
+
+// Tuning options (rbd_set_option): one instance, owned by the COMMON unit; relaxed atomics -- an option
+// only ever selects between kernels that compute the same result.
+extern "C" __attribute__((visibility("hidden"))) std::atomic<int>* rbd_option_slot(int option);
+#ifdef RBD_TU_COMMON
+extern "C" std::atomic<int>* rbd_option_slot(int option) {
+  static std::atomic<int> slots[RBD_OPT_COUNT_];
+  return option >= 0 && option < RBD_OPT_COUNT_ ? &slots[option] : nullptr;
+}
+#endif
+static inline int rbd_option(int option) { return rbd_option_slot(option)->load(std::memory_order_relaxed); }
 
 // The forward-dynamics units reuse the kernels of the RNEA / MINV / GRAD units through these entry
 // points instead of instantiating the same templates a second time (Atlas: the fp64 gradient kernel
@@ -1167,13 +1160,53 @@ int hip_fail(hipError_t e, const char* where) {
   return (int)e > 0 ? (int)e : 1;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is needed once per kernel (and device), not per
+// launch: the granted sizes are remembered.
 template <class K>
 int ensure_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (bytes <= 64 * 1024) return 0;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> granted[RBD_MAX_DEVICES];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const void* key = reinterpret_cast<const void*>(kernel);
+  const int slot = dev >= 0 && dev < RBD_MAX_DEVICES ? dev : 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = granted[slot].find(key);
+    if (it != granted[slot].end() && it->second >= bytes) return 0;
   }
+  hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  std::lock_guard<std::mutex> g(mu);
+  granted[slot][key] = bytes;
+  return 0;
+}
+
+// Blocks of `threads` threads and `lds` bytes that are resident at once on the current device
+// (occupancy per CU x CUs), remembered per kernel and device: the grid of the tile-walking kernels.
+template <class K>
+int resident_blocks(K kernel, int threads, size_t lds, int* out) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> known[RBD_MAX_DEVICES];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const void* key = reinterpret_cast<const void*>(kernel);
+  const int slot = dev >= 0 && dev < RBD_MAX_DEVICES ? dev : 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = known[slot].find(key);
+    if (it != known[slot].end()) { *out = it->second; return 0; }
+  }
+  int per_cu = 0, cus = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds);
+  if (e != hipSuccess) return hip_fail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+  e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute(MultiprocessorCount)");
+  const int n = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+  std::lock_guard<std::mutex> g(mu);
+  known[slot][key] = n;
+  *out = n;
   return 0;
 }
 
@@ -1255,6 +1288,34 @@ int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_
   return 0;
 }
 
+// One-lane chain kernel (rbd_idsva.h): the grid is what is resident at once, every block walks tiles.
+template <class T, bool HAS_QDD, bool FDG>
+int idsva_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                 T* c, T* dc_du, void* stream, const T* minv_in) {
+  using namespace rbdk;
+  const int64_t tiles = (B + 63) / 64;
+  if (tiles > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+  if ((reinterpret_cast<uintptr_t>(dc_du) & 15u) != 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: dc_du must be 16-byte aligned");
+  const size_t lds = sizeof(T) * (size_t)64 * IDS_TS;
+  if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
+  int rc, resident = 0;
+  auto k = rnea_grad_idsva_kernel<T, HAS_QDD, FDG>;
+  if ((rc = ensure_lds(k, lds)) != 0) return rc;
+  if ((rc = resident_blocks(k, 64, lds, &resident)) != 0) return rc;
+#ifdef RBD_EXP_IDS_GRID_TILES
+  resident = 0x7fffffff;                   // experiment: one block per tile (no tile walking)
+#endif
+#ifdef RBD_EXP_IDS_GRID_SCALE
+  resident = resident * RBD_EXP_IDS_GRID_SCALE / 8;   // experiment: k/8 of the resident blocks
+#endif
+  const int64_t blocks = tiles < resident ? tiles : resident;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping,
+                     (long long)B, c, dc_du, minv_in);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
+  return 0;
+}
+
 // One instantiation per (T, HAS_QDD): the forward-dynamics units only ever need HAS_QDD = true.
 template <class T, bool HAS_QDD>
 int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
@@ -1265,15 +1326,9 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
   constexpr bool TREE_BUILT = GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
   if constexpr (TREE_BUILT) {
-    static const int forced = [] {
-      const char* e = std::getenv("RBD_GRAD_KERNEL");
-      if (e && std::strcmp(e, "tree") == 0) return 1;
-      if (e && (std::strcmp(e, "column") == 0 || std::strcmp(e, "chain") == 0)) return -1;
-      return 0;
-    }();
     constexpr size_t lds = tree_lds_bytes<T>();
     static_assert(!TREE_ONLY || lds <= 160 * 1024, "tree kernel is the only gradient kernel of this robot but does not fit LDS");
-    const bool use_tree = TREE_ONLY || forced > 0;
+    const bool use_tree = TREE_ONLY || rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE;
     if (use_tree && lds <= 160 * 1024) {
       const int64_t blocks = (B + 63) / 64;
       if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
@@ -1289,18 +1344,8 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
   if constexpr (TREE_ONLY) {
     return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: no kernel");   // unreachable (static_assert above)
   } else if constexpr (grad_chain_kernel<T>()) {
-    // one lane per configuration (rbd_idsva.h)
-    const int64_t blocks = (B + 63) / 64;
-    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
-    const size_t lds = sizeof(T) * (size_t)64 * GRAD_TS;
-    if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
-    int rc;
-    auto k = rnea_grad_idsva_kernel<T, HAS_QDD>;
-    if ((rc = ensure_lds(k, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du, (const T*)nullptr);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
-    return 0;
+    // one lane per configuration, tile-walking blocks (rbd_idsva.h)
+    return idsva_launch<T, HAS_QDD, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
   } else {
     return rnea_grad_launch1<T, HAS_QDD, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
   }
@@ -1314,6 +1359,22 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
   if (qdd) return rnea_grad_launch_q<T, true>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
   return rnea_grad_launch_q<T, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+}
+
+// name of the kernel rnea_grad_launch<T> would run (HAS_QDD = true) under the current options
+template <class T>
+int grad_kernel_name(int64_t B, char* buf, size_t len) {
+  using namespace rbdk;
+  (void)B;
+  const char* t = sizeof(T) == 4 ? "float" : "double";
+  constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
+  constexpr bool TREE_BUILT = GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
+  bool tree = TREE_ONLY;
+  if constexpr (TREE_BUILT) tree = tree || (rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE && tree_lds_bytes<T>() <= 160 * 1024);
+  if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);
+  else if (grad_chain_kernel<T>()) std::snprintf(buf, len, "rnea_grad_idsva_kernel<%s,true,false>", t);
+  else std::snprintf(buf, len, "rnea_grad_kernel<%s,true,false>", t);
+  return 0;
 }
 
 #endif  // RBD_NEED_GRAD
@@ -1348,7 +1409,8 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   T* ws = reinterpret_cast<T*>(workspace);
   // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
   // otherwise eight lanes per configuration (rbd_minv_ia8.h)
-  if (B >= 64 * 1024 * 4 || std::getenv("RBD_MINV_IA1") != nullptr) {
+  const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
+  if (pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4)) {
     hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
   } else {
     hipLaunchKernelGGL(minv_ia8_kernel<T>, dim3((unsigned)((B + 7) / 8), n_groups()), dim3(64), 0, s, q, (long long)B, ws);
@@ -1364,6 +1426,16 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase B launch");
   return 0;
   }
+}
+
+// name of the dominant kernel minv_launch<T> would run for B rows under the current options
+template <class T>
+int minv_kernel_name(int64_t B, char* buf, size_t len) {
+  (void)B;
+  const char* t = sizeof(T) == 4 ? "float" : "double";
+  if (rbdk::MINV_USE_LANE) std::snprintf(buf, len, "minv_lane_kernel<%s>", t);
+  else std::snprintf(buf, len, "minv_cols_kernel<%s>", t);
+  return 0;
 }
 
 #endif  // RBD_NEED_MINV
@@ -1459,16 +1531,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
   if constexpr (grad_chain_kernel<T>() && grad_max_rows() == N) {
-    const int64_t blocks = (B + 63) / 64;
-    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
-    const size_t lds = sizeof(T) * (size_t)64 * GRAD_TS;
-    auto k = rnea_grad_idsva_kernel<T, true, true>;
-    if ((rc = ensure_lds(k, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)qdd_buf, gravity, 0,
-                       (long long)B, (T*)nullptr, dqdd_du, (const T*)Mi);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad launch");
-    return 0;
+    return idsva_launch<T, true, true>(q, qd, (const T*)qdd_buf, gravity, 0, B, (T*)nullptr, dqdd_du, stream, (const T*)Mi);
   } else if constexpr (GRAD_ACC_IN_REGS) {
     return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);
   } else {
@@ -1554,9 +1617,53 @@ int minv_fpass_launch(const T* q, int64_t B, T* Minv, T* F, const T* U, const T*
 
 extern "C" {
 
+// kernel names: every family unit answers for its own kernels (the selection logic lives there)
+__attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f32(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len);
+#ifdef RBD_TU_GRAD_F32
+int rbd_grad_kernel_name_f32(int64_t B, char* buf, size_t len) { return grad_kernel_name<float>(B, buf, len); }
+#endif
+#ifdef RBD_TU_GRAD_F64
+int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len) { return grad_kernel_name<double>(B, buf, len); }
+#endif
+#ifdef RBD_TU_MINV_F32
+int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len) { return minv_kernel_name<float>(B, buf, len); }
+#endif
+#ifdef RBD_TU_MINV_F64
+int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len) { return minv_kernel_name<double>(B, buf, len); }
+#endif
+
 #ifdef RBD_TU_COMMON
 int rbd_abi_version(void) { return RBD_ABI_VERSION; }
 const char* rbd_last_error(void) { return rbd_err_buf(); }
+
+int rbd_set_option(int option, int value) {
+  std::atomic<int>* s = rbd_option_slot(option);
+  if (!s) return fail(RBD_ERR_ARG, "rbd_set_option: unknown option");
+  if (value < 0 || value > 2 || (option == RBD_OPT_GRAD_KERNEL && value > 1)) return fail(RBD_ERR_ARG, "rbd_set_option: value out of range");
+  s->store(value, std::memory_order_relaxed);
+  return 0;
+}
+int rbd_get_option(int option) {
+  std::atomic<int>* s = rbd_option_slot(option);
+  return s ? s->load(std::memory_order_relaxed) : RBD_ERR_ARG;
+}
+int rbd_kernel_name(int op, int elem_size, int64_t B, char* buf, size_t len) {
+  if (!buf || len == 0 || (elem_size != 4 && elem_size != 8)) return fail(RBD_ERR_ARG, "rbd_kernel_name: bad arguments");
+  switch (op) {
+    case RBD_OP_RNEA:
+      std::snprintf(buf, len, "rnea_kernel<%s,*,*>", elem_size == 4 ? "float" : "double");
+      return 0;
+    case RBD_OP_RNEA_GRAD:
+      return elem_size == 4 ? rbd_grad_kernel_name_f32(B, buf, len) : rbd_grad_kernel_name_f64(B, buf, len);
+    case RBD_OP_MINV:
+      return elem_size == 4 ? rbd_minv_kernel_name_f32(B, buf, len) : rbd_minv_kernel_name_f64(B, buf, len);
+    default:
+      return fail(RBD_ERR_ARG, "rbd_kernel_name: unknown op");
+  }
+}
 
 int rbd_model_info(rbd_model_info_t* out) {
   if (!out) return fail(RBD_ERR_ARG, "rbd_model_info: out is null");

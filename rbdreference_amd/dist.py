@@ -54,9 +54,16 @@ def check_same_model(model_hash: str, group=None) -> None:
         raise RuntimeError(f"ranks hold different robots: {hashes}")
 
 
+def _global_rank(group, r: int) -> int:
+    """Group-local rank -> the global rank ``dist.isend`` / ``dist.recv`` expect as peer."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
 def scatter_rows(x: Optional[torch.Tensor], B: int, row_shape: Sequence[int], dtype, device,
                  src: int = 0, group=None) -> torch.Tensor:
-    """Rank ``src`` holds ``x`` = [B, *row_shape]; every rank receives its contiguous shard."""
+    """Rank ``src`` (a rank OF ``group``) holds ``x`` = [B, *row_shape]; every rank of the group
+    receives its contiguous shard (point-to-point sends: xGMI is a full mesh, every shard travels
+    over its own link)."""
     world, rank = _world(group)
     if world == 1:
         return x
@@ -69,11 +76,11 @@ def scatter_rows(x: Optional[torch.Tensor], B: int, row_shape: Sequence[int], dt
             if r == src:
                 out.copy_(chunks[r])
             elif sizes[r] > 0:
-                reqs.append(dist.isend(chunks[r].contiguous(), dst=r, group=group))
+                reqs.append(dist.isend(chunks[r].contiguous(), dst=_global_rank(group, r), group=group))
         for q in reqs:
             q.wait()
     elif sizes[rank] > 0:
-        dist.recv(out, src=src, group=group)
+        dist.recv(out, src=_global_rank(group, src), group=group)
     return out
 
 
@@ -91,8 +98,10 @@ def all_gather_rows(local: torch.Tensor, B: int, group=None) -> torch.Tensor:
         pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
     buf = torch.empty((world * mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, pad.contiguous(), group=group) if hasattr(dist, "all_gather_into_tensor") \
-        and local.device.type == "cuda" else dist.all_gather(list(buf.split(mx, dim=0)), pad.contiguous(), group=group)
+    if local.device.type == "cuda":           # RCCL: one collective into the flat buffer
+        dist.all_gather_into_tensor(buf, pad.contiguous(), group=group)
+    else:                                     # gloo (CPU tests): list form
+        dist.all_gather(list(buf.split(mx, dim=0)), pad.contiguous(), group=group)
     if all(s == mx for s in sizes):
         return buf
     return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
@@ -124,7 +133,11 @@ class ShardedRBD:
         B = q.shape[0]
         sl = self.local_slice(B)
         out = self._grad(q[sl], qd[sl], None if qdd is None else qdd[sl], **kw)
-        return all_gather_rows(out, B, self.group) if gather else out
+        if not gather:
+            return out
+        if isinstance(out, tuple):            # return_c=True -> (c, dc_du): gather each
+            return tuple(all_gather_rows(o, B, self.group) for o in out)
+        return all_gather_rows(out, B, self.group)
 
     def minv(self, q, gather: bool = False, **kw):
         B = q.shape[0]

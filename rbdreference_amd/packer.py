@@ -22,7 +22,7 @@ from typing import List
 
 import numpy as np
 
-__all__ = ["PackedModel", "pack_robot", "emit_header", "ABI_VERSION"]
+__all__ = ["PackedModel", "pack_robot", "emit_header", "safe_name", "ABI_VERSION"]
 
 ABI_VERSION = 1
 
@@ -148,14 +148,23 @@ def _hexf(v: float) -> str:
     return v.hex()
 
 
+def safe_name(name: str) -> str:
+    """The robot name as it may appear in generated C++ and in file names: ``[A-Za-z0-9_]`` only, at
+    most 63 characters (``rbd_model_info_t.name`` holds 64 bytes).  The name comes from the caller or
+    from a URDF's ``<robot name=...>`` -- i.e. from untrusted text -- and the generated header is
+    compiled and dlopen'ed in-process, so nothing else may pass."""
+    s = "".join(ch if (ch.isascii() and (ch.isalnum() or ch == "_")) else "_" for ch in str(name))[:63]
+    return s or "robot"
+
+
 def emit_header(m: PackedModel) -> str:
     """C++ header text consumed by csrc/rbd_kernels.hip (``-include`` on the hipcc command line).
     Floating-point constants are written as hex-float literals, i.e. bit-exact."""
     n = m.n
     L = []
-    L.append(f"// GENERATED by rbdreference_amd/packer.py -- model {m.name!r}, hash {m.hash}. Do not edit.")
+    L.append(f"// GENERATED by rbdreference_amd/packer.py -- model {safe_name(m.name)}, hash {m.hash}. Do not edit.")
     L.append("#pragma once")
-    L.append(f'#define RBD_MODEL_NAME "{m.name}"')
+    L.append(f'#define RBD_MODEL_NAME "{safe_name(m.name)}"')
     L.append(f"#define RBD_MODEL_HASH 0x{m.hash}ULL")
     L.append(f"#define RBD_ABI_VERSION {ABI_VERSION}")
     L.append("namespace rbdm {")

@@ -43,7 +43,10 @@ def _worker(rank, world, port, B, q_all, ret):
         from rbdreference_amd.dist import ShardedRBD, all_gather_rows, scatter_rows
         om = orc.model_from_robot(iiwa_like())
 
-        def grad(q, qd, qdd, **kw):
+        def grad(q, qd, qdd, return_c=False, **kw):
+            if return_c:
+                c, dc = orc.rnea_grad(om, q.numpy(), qd.numpy(), qdd.numpy(), return_c=True)
+                return torch.from_numpy(c), torch.from_numpy(dc)
             return torch.from_numpy(orc.rnea_grad(om, q.numpy(), qd.numpy(), qdd.numpy()))
 
         def minv(q, **kw):
@@ -60,6 +63,22 @@ def _worker(rank, world, port, B, q_all, ret):
         assert torch.equal(qs, q[a:b])
         again = all_gather_rows(grad(qs, qd[a:b], qdd[a:b]), B)
         assert torch.equal(again, full)
+        # return_c=True makes the compute return (c, dc_du): both are gathered
+        c_full, dc_full = sh.rnea_grad(q, qd, qdd, gather=True, return_c=True)
+        assert torch.equal(dc_full, full) and c_full.shape == (B, 7)
+        # a sub-group whose local rank 0 is NOT global rank 0: scatter_rows takes group-local ranks
+        # and must translate them for the point-to-point calls
+        if world >= 3:
+            sub = dist.new_group(ranks=list(range(1, world)))          # every rank calls new_group
+            if rank >= 1:
+                sw, sr = dist.get_world_size(sub), dist.get_rank(sub)
+                sa, sb = shard_bounds(B, sw, sr)
+                qs2 = scatter_rows(q if sr == 0 else None, B, (7,), q.dtype, "cpu", src=0, group=sub)
+                assert torch.equal(qs2, q[sa:sb])
+                g2 = all_gather_rows(grad(qs2, qd[sa:sb], qdd[sa:sb]), B, group=sub)
+                assert torch.equal(g2, full)
+                sh2 = ShardedRBD(None, group=sub, compute_rnea_grad=grad, compute_minv=minv, model_hash="abc")
+                assert torch.equal(sh2.minv(q, gather=True), Mi)
         if rank == 0:
             ret["full"] = full.numpy(); ret["minv"] = Mi.numpy()
         # mismatching robots must be detected
