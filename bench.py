@@ -342,6 +342,41 @@ def main():
             extra["cfg1_iiwa_rnea_grad_B4096_f32"] = {"ms_per_launch": ms, "evals_per_s": 4096 / (ms * 1e-3)}
             ms = time_extra_ms(lambda: rbd.rnea(q4, qd4, qdd4), 100, 10)
             extra["cfg1_iiwa_rnea_cvaf_B4096_f32_api"] = {"ms_per_call": ms, "evals_per_s": 4096 / (ms * 1e-3)}
+            # configs[1] as one call: rnea + rnea_grad -> (c, v, a, f, dc_du), eager launches back to back and
+            # the same launches replayed from a HIP graph (launch-amortised)
+            try:
+                from rbdreference_amd._lib import RBD_OP_RNEA_GRAD as _OP
+                o4 = [torch.empty(sh, device=dev, dtype=torch.float32) for sh in
+                      ((4096, 7), (4096, 6, 7), (4096, 6, 7), (4096, 6, 7), (4096, 7, 14))]
+                fn4 = rbd._fn("rbd_rnea_with_grad", torch.float32)
+
+                def fused():
+                    st = torch.cuda.current_stream(dev).cuda_stream
+                    rc = fn4(q4.data_ptr(), qd4.data_ptr(), qdd4.data_ptr(), -9.81, 0, 4096,
+                             *[t.data_ptr() for t in o4], st)
+                    if rc != 0:
+                        rbd._lib.check(rc)
+                ms = time_extra_ms(fused, 200, 20)
+                ent = {"ms_per_launch_eager": ms, "evals_per_s_eager": 4096 / (ms * 1e-3),
+                       "kernel": rbd._lib.kernel_name(_OP, 4, 4096), "outputs": "c, v, a, f, dc_du",
+                       "alg_GBps_eager": 4096 * (22 * 7 + 2 * 49) * 4 / (ms * 1e-3) / 1e9}
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    fused()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                NG = 50
+                with torch.cuda.graph(gr):
+                    for _ in range(NG):
+                        fused()
+                msg = time_extra_ms(gr.replay, 20, 3) / NG
+                ent["ms_per_launch_graph"] = msg
+                ent["evals_per_s_graph"] = 4096 / (msg * 1e-3)
+                extra["cfg1_iiwa_rnea+rnea_grad_one_call_B4096_f32"] = ent
+            except Exception as e:
+                extra["cfg1_one_call_error"] = repr(e)
             Bq = q.shape[0]
             ms = time_extra_ms(lambda: rbd.minv(q), 10, 2)
             extra["iiwa_minv_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),

@@ -54,7 +54,9 @@ int rbd_model_info(rbd_model_info_t* out);
  * where the override is built into the library (tests run every kernel of every robot this way;
  * a value the library cannot honour is ignored).  Options only ever select between kernels that
  * compute the same result.  Process-wide, thread-safe, no environment variables are read.
- *   RBD_OPT_GRAD_KERNEL    rbd_rnea_grad: AUTO | TREE (chain-by-chain world-frame kernel)
+ *   RBD_OPT_GRAD_KERNEL    rbd_rnea_grad: AUTO | TREE (chain-by-chain world-frame kernel) | COLS (one
+ *                          lane per derivative column: AUTO picks it for small batches) | BATCH (the
+ *                          robot's batch-parallel kernel at every batch size)
  *   RBD_OPT_MINV_PHASE_A   rbd_minv, two-phase robots: AUTO | LANE (one lane per configuration) |
  *                          IA8 (eight lanes per configuration)
  * rbd_kernel_name writes the name of the kernel (the dominant one of a multi-launch entry point) that
@@ -64,6 +66,8 @@ int rbd_model_info(rbd_model_info_t* out);
 #define RBD_OPT_COUNT_ 2
 #define RBD_GRAD_KERNEL_AUTO 0
 #define RBD_GRAD_KERNEL_TREE 1
+#define RBD_GRAD_KERNEL_COLS 2
+#define RBD_GRAD_KERNEL_BATCH 3
 #define RBD_MINV_PHASE_A_AUTO 0
 #define RBD_MINV_PHASE_A_LANE 1
 #define RBD_MINV_PHASE_A_IA8 2
@@ -124,6 +128,16 @@ int rbd_rnea_grad_f32(const float* q, const float* qd, const float* qdd, float g
                       int use_damping, int64_t B, float* c, float* dc_du, void* stream);
 int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, double gravity,
                       int use_damping, int64_t B, double* c, double* dc_du, void* stream);
+
+/* rnea + rnea_grad in one call: everything RBDReference.rnea (:623-628) and RBDReference.rnea_grad
+ * (:1345-1368) return for the same (q, qd, qdd) -- the reference's rnea_grad runs rnea internally
+ * (:1353) and drops its outputs.  c [B,n]; v, a, f [B,6,n] (f accumulated); dc_du [B,n,2n]; all
+ * non-null.  For small batches this is ONE launch (one lane per derivative column), otherwise the rnea
+ * kernel followed by the gradient kernel on `stream`. */
+int rbd_rnea_with_grad_f32(const float* q, const float* qd, const float* qdd, float gravity, int use_damping,
+                           int64_t B, float* c, float* v, float* a, float* f, float* dc_du, void* stream);
+int rbd_rnea_with_grad_f64(const double* q, const double* qd, const double* qdd, double gravity, int use_damping,
+                           int64_t B, double* c, double* v, double* a, double* f, double* dc_du, void* stream);
 
 /* RBDReference.minv(q, output_dense)                      (RBDReference.py:785-806)
  *   Minv : [B, n, n].  output_dense != 0: symmetric matrix (:799-804).  output_dense == 0: upper

@@ -17,7 +17,7 @@ RBD_MAX_BODIES = 64
 RBD_ERR_ARG, RBD_ERR_UNSUPPORTED, RBD_ERR_WORKSPACE = -1, -2, -3
 # rbd_set_option / rbd_kernel_name constants (include/rbd_hip.h)
 RBD_OPT_GRAD_KERNEL, RBD_OPT_MINV_PHASE_A = 0, 1
-RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_TREE = 0, 1
+RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_TREE, RBD_GRAD_KERNEL_COLS, RBD_GRAD_KERNEL_BATCH = 0, 1, 2, 3
 RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8 = 0, 1, 2
 RBD_OP_RNEA, RBD_OP_RNEA_GRAD, RBD_OP_MINV = 0, 1, 2
 
@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "rbd_abi_version", "rbd_last_error", "rbd_model_info",
     "rbd_set_option", "rbd_get_option", "rbd_kernel_name",
     "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
+    "rbd_rnea_with_grad_f32", "rbd_rnea_with_grad_f64",
     "rbd_rnea_fpass_f32", "rbd_rnea_fpass_f64", "rbd_rnea_bpass_f32", "rbd_rnea_bpass_f64",
     "rbd_minv_workspace_bytes", "rbd_minv_f32", "rbd_minv_f64",
     "rbd_crba_f32", "rbd_crba_f64",
@@ -80,6 +81,9 @@ def _declare(lib):
         f = getattr(lib, f"rbd_rnea_grad_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int, c_int64, c_void_p, c_void_p, c_void_p]
+        f = getattr(lib, f"rbd_rnea_with_grad_{sfx}")
+        f.restype = c_int
+        f.argtypes = [c_void_p, c_void_p, c_void_p, ft, c_int, c_int64] + [c_void_p] * 6
         f = getattr(lib, f"rbd_minv_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]

@@ -302,6 +302,24 @@ class RBDReference:
             return self._ret(c, unb, is_np), self._ret(dc, unb, is_np)
         return self._ret(dc, unb, is_np)
 
+    def rnea_and_grad(self, q, qd, qdd=None, GRAVITY=-9.81, USE_VELOCITY_DAMPING=False):
+        """``rnea`` and ``rnea_grad`` of the same inputs in one call -> ``(c, v, a, f, dc_du)``: what the
+        reference computes inside ``rnea_grad`` (``RBDReference.py:1353`` runs ``rnea`` and drops its
+        outputs).  For small batches this is one launch of the column kernel."""
+        (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
+        B = q.shape[0]
+        with torch.cuda.device(dev):
+            c = torch.empty((B, self.n), device=dev, dtype=dt)
+            v = torch.empty((B, 6, self.n), device=dev, dtype=dt)
+            a = torch.empty_like(v)
+            f = torch.empty_like(v)
+            dc = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            self._lib.check(self._fn("rbd_rnea_with_grad", dt)(
+                self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B,
+                self._ptr(c), self._ptr(v), self._ptr(a), self._ptr(f), self._ptr(dc), st))
+        return tuple(self._ret(t, unb, is_np) for t in (c, v, a, f, dc))
+
     def minv(self, q, output_dense=True):
         """RBDReference.minv (``RBDReference.py:785-806``) -> ``(n, n)`` per configuration.
         ``output_dense=False`` returns the upper triangle with a ZERO strict lower triangle (the

@@ -742,6 +742,9 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
 }  // namespace rbdk
 #include "rbd_idsva.h"
 #include "rbd_idsva_tree.h"
+#ifdef RBD_NEED_GRAD
+#include "rbd_grad_cols.h"
+#endif
 namespace rbdk {
 #ifdef RBD_NO_IDSVA
 constexpr bool GRAD_USE_IDSVA = false;
@@ -1316,11 +1319,41 @@ int idsva_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_dampi
   return 0;
 }
 
+// Small batches: one lane per (configuration, derivative column) (rbd_grad_cols.h).  Chosen when the
+// batch-parallel kernels would leave most of the chip idle: at most two of its waves per SIMD.
+constexpr int64_t GRAD_COLS_MAX_WAVES = 2048;
+template <class T>
+inline bool grad_use_cols(int64_t B) {
+  using namespace rbdk;
+  if (!grad_cols_ok<T>()) return false;
+  const int opt = rbd_option(RBD_OPT_GRAD_KERNEL);
+  if (opt == RBD_GRAD_KERNEL_COLS) return true;
+  if (opt != RBD_GRAD_KERNEL_AUTO) return false;
+  return (B + GC_CPW - 1) / GC_CPW <= GRAD_COLS_MAX_WAVES;
+}
+template <class T, bool HAS_QDD>
+int grad_cols_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                     T* c, T* v, T* a, T* f, T* dc_du, void* stream) {
+  using namespace rbdk;
+  if constexpr (!grad_cols_ok<T>()) {
+    return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: the column kernel is not built for this robot size");
+  } else {
+    const int64_t blocks = (B + GC_CPW - 1) / GC_CPW;
+    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+    hipLaunchKernelGGL((rnea_grad_cols_kernel<T, HAS_QDD>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd,
+                       gravity, use_damping, (long long)B, c, v, a, f, dc_du);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad (column kernel) launch");
+    return 0;
+  }
+}
+
 // One instantiation per (T, HAS_QDD): the forward-dynamics units only ever need HAS_QDD = true.
 template <class T, bool HAS_QDD>
 int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
                        T* c, T* dc_du, void* stream) {
   using namespace rbdk;
+  if (grad_use_cols<T>(B)) return grad_cols_launch<T, HAS_QDD>(q, qd, qdd, gravity, use_damping, B, c, nullptr, nullptr, nullptr, dc_du, stream);
   // fp32 robots whose default is the tree kernel never build the column kernel (Atlas: 404 VGPRs of
   // code nobody runs); fp64 x big tree would need > 512 VGPRs and is not built either.
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
@@ -1361,12 +1394,31 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   return rnea_grad_launch_q<T, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
 }
 
+// rnea + rnea_grad: (c, v, a, f, dc_du).  One launch when the column kernel serves the batch, otherwise the
+// rnea kernel of the RNEA unit followed by the gradient kernel on the same stream.
+template <class T>
+int rnea_with_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
+                          T* c, T* v, T* a, T* f, T* dc_du, void* stream) {
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !c || !v || !a || !f || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: q, qd, c, v, a, f, dc_du must be non-null");
+  if (grad_use_cols<T>(B)) {
+    if (qdd) return grad_cols_launch<T, true>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+    return grad_cols_launch<T, false>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+  }
+  int rc;
+  if constexpr (sizeof(T) == 4) rc = rbd_rnea_f32((const float*)q, (const float*)qd, (const float*)qdd, (float)gravity, B, (float*)c, (float*)v, (float*)a, (float*)f, stream);
+  else rc = rbd_rnea_f64((const double*)q, (const double*)qd, (const double*)qdd, (double)gravity, B, (double*)c, (double*)v, (double*)a, (double*)f, stream);
+  if (rc != 0) return rc;
+  return rnea_grad_launch<T>(q, qd, qdd, gravity, use_damping, B, nullptr, dc_du, stream);
+}
+
 // name of the kernel rnea_grad_launch<T> would run (HAS_QDD = true) under the current options
 template <class T>
 int grad_kernel_name(int64_t B, char* buf, size_t len) {
   using namespace rbdk;
-  (void)B;
   const char* t = sizeof(T) == 4 ? "float" : "double";
+  if (grad_use_cols<T>(B)) { std::snprintf(buf, len, "rnea_grad_cols_kernel<%s,true>", t); return 0; }
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
   constexpr bool TREE_BUILT = GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
   bool tree = TREE_ONLY;
@@ -1642,7 +1694,8 @@ const char* rbd_last_error(void) { return rbd_err_buf(); }
 int rbd_set_option(int option, int value) {
   std::atomic<int>* s = rbd_option_slot(option);
   if (!s) return fail(RBD_ERR_ARG, "rbd_set_option: unknown option");
-  if (value < 0 || value > 2 || (option == RBD_OPT_GRAD_KERNEL && value > 1)) return fail(RBD_ERR_ARG, "rbd_set_option: value out of range");
+  if (value < 0 || value > (option == RBD_OPT_GRAD_KERNEL ? RBD_GRAD_KERNEL_BATCH : RBD_MINV_PHASE_A_IA8))
+    return fail(RBD_ERR_ARG, "rbd_set_option: value out of range");
   s->store(value, std::memory_order_relaxed);
   return 0;
 }
@@ -1731,6 +1784,16 @@ int rbd_rnea_grad_f32(const float* q, const float* qd, const float* qdd, float g
 int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, double gravity,
                       int use_damping, int64_t B, double* c, double* dc_du, void* stream) {
   return rnea_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+}
+int rbd_rnea_with_grad_f64(const double* q, const double* qd, const double* qdd, double gravity, int use_damping, int64_t B,
+                           double* c, double* v, double* a, double* f, double* dc_du, void* stream) {
+  return rnea_with_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+}
+#endif
+#ifdef RBD_TU_GRAD_F32
+int rbd_rnea_with_grad_f32(const float* q, const float* qd, const float* qdd, float gravity, int use_damping, int64_t B,
+                           float* c, float* v, float* a, float* f, float* dc_du, void* stream) {
+  return rnea_with_grad_launch<float>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
 }
 #endif
 #ifdef RBD_TU_MINV_F32

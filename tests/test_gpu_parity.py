@@ -73,15 +73,47 @@ def test_rnea_vs_golden(name, prec):
     check("c (c-only kernel)", c1, g["c"], tol)
 
 
+@pytest.fixture(params=["batch", "cols"])
+def grad_kernel(request):
+    """Every rnea_grad test runs on the robot's batch-parallel kernel AND on the column kernel (which
+    AUTO would pick for these small batches): rbd_set_option, restored afterwards."""
+    from rbdreference_amd._lib import (RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_BATCH, RBD_GRAD_KERNEL_COLS,
+                                       RBD_OPT_GRAD_KERNEL)
+    want = RBD_GRAD_KERNEL_BATCH if request.param == "batch" else RBD_GRAD_KERNEL_COLS
+    touched = []
+
+    def use(rbd):
+        rbd._lib.set_option(RBD_OPT_GRAD_KERNEL, want)
+        touched.append(rbd)
+        return request.param
+    yield use
+    for rbd in touched:
+        rbd._lib.set_option(RBD_OPT_GRAD_KERNEL, RBD_GRAD_KERNEL_AUTO)
+
+
 @pytest.mark.parametrize("name", all_golden_names())
-def test_rnea_grad_vs_golden(name, prec):
+def test_rnea_grad_vs_golden(name, prec, grad_kernel):
+    from rbdreference_amd._lib import RBD_OP_RNEA_GRAD
     dt, tol = prec
     g = load_golden(name); rbd = rbd_for(name)
+    which = grad_kernel(rbd)
+    if which == "cols" and "cols" not in rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4 if dt == _torch().float32 else 8, 8):
+        pytest.skip("the column kernel is not built for this robot size / precision")
+    assert ("cols" in rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4 if dt == _torch().float32 else 8, 8)) == (which == "cols")
     q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
     c, dc = rbd.rnea_grad(q, qd, qdd, return_c=True)
     check("dc_du", dc, g["dc_du"], tol); check("c", c, g["c"], tol)
     check("dc_du_damped", rbd.rnea_grad(q, qd, qdd, USE_VELOCITY_DAMPING=True), g["dc_du_damped"], tol)
     check("dc_du_noqdd", rbd.rnea_grad(q, qd), g["dc_du_noqdd"], tol)
+    # rnea + rnea_grad from one call (one launch on the column kernel)
+    c2, v, a, f, dc2 = rbd.rnea_and_grad(q, qd, qdd)
+    check("c", c2, g["c"], tol); check("v", v, g["fpass_v"], tol); check("a", a, g["fpass_a"], tol)
+    check("f (accumulated)", f, g["f_acc"], tol); check("dc_du", dc2, g["dc_du"], tol)
+    c3, _, _, _, dc3 = rbd.rnea_and_grad(q, qd, USE_VELOCITY_DAMPING=True)
+    check("c_noqdd", c3, g["c_noqdd"], tol)
+    want = np.concatenate((g["dc_du_noqdd"][..., :rbd.n], g["dc_du_noqdd"][..., rbd.n:] +
+                           (g["dc_du_damped"] - g["dc_du"])[..., rbd.n:]), axis=-1)
+    check("dc_du damped, qdd=None", dc3, want, tol)
 
 
 @pytest.mark.parametrize("name", all_golden_names())
@@ -99,11 +131,12 @@ def test_minv_vs_golden(name, prec):
 
 @pytest.mark.parametrize("name", ["iiwa_like", "quadruped_like", "atlas_like"])
 @pytest.mark.parametrize("B", [1, 31, 33, 257, 1000])
-def test_batch_sizes_vs_oracle(name, B):
+def test_batch_sizes_vs_oracle(name, B, grad_kernel):
     """Ragged batches (not multiples of the 32/64-configuration blocks) against the oracle."""
     from oracle import rbd_oracle as orc
     torch = _torch()
     robot = make_robot(name); rbd = rbd_for(name); om = orc.model_from_robot(robot)
+    grad_kernel(rbd)
     rng = np.random.default_rng(1000 + B)
     n = rbd.n
     q = rng.uniform(-np.pi, np.pi, (B, n)); qd = rng.uniform(-1, 1, (B, n)); qdd = rng.uniform(-1, 1, (B, n))

@@ -170,6 +170,8 @@ def test_fp32_kernels_of_built_libraries_do_not_spill():
             name = line.split("vgpr=")[0].strip()
             spill = int(line.rsplit("spill=", 1)[1])
             scratch = int(line.split("scratch=")[1].split()[0])
-            if "<float" in name and (spill or scratch):
+            # `spill` with scratch == 0 are copies into the accumulator half of a lone wave's 512-entry
+            # register file (v_accvgpr_write / read): registers, not memory traffic
+            if "<float" in name and scratch:
                 bad.append((os.path.basename(lib), name, spill, scratch))
     assert not bad, bad
