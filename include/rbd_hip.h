@@ -16,6 +16,13 @@
  *     rbd_last_error() returns a thread-local message for the last non-zero return;
  *   - no C++ exceptions cross this boundary; the model is immutable, so concurrent calls from
  *     several host threads / streams are safe.
+ *
+ * Floating-base robots (RBDReference.py:585-593, :652-691, :761-779; robot.floating_base): body 0
+ * owns indices 0..5 of q, qd, qdd, c (q[0:6] = px, py, pz, rx, ry, rz of the world -> base transform,
+ * qd[0:6] = the base twist in base coordinates), body i >= 1 owns index i + 5; "n" in the shapes
+ * below then reads nv = n + 5 for q, qd, qdd, c, u, Minv and stays the body count for v, a, f.  Such a
+ * library serves rbd_rnea, rbd_minv and rbd_forward_dynamics; every other entry point returns
+ * RBD_ERR_UNSUPPORTED (the reference's own crba / aba raise for floating bases).
  */
 #ifndef RBD_HIP_H
 #define RBD_HIP_H
@@ -40,8 +47,10 @@ typedef struct rbd_model_info {
   uint64_t hash;                      /* first 64 bits of sha256 over the packed model       */
   char name[64];
   int32_t parent[RBD_MAX_BODIES];     /* -1 = child of the fixed base                        */
-  int32_t joint_type[RBD_MAX_BODIES]; /* 0 revolute, 1 prismatic                             */
+  int32_t joint_type[RBD_MAX_BODIES]; /* 0 revolute, 1 prismatic, 2 = the 6-DoF floating base */
   int32_t joint_axis[RBD_MAX_BODIES]; /* 0/1/2 = x/y/z of the body frame                     */
+  int32_t floating_base;              /* 1: body 0 is attached by a 6-DoF joint (S = eye(6)), */
+  int32_t nv;                         /*    and q, qd, qdd, c have nv = n + 5 columns (else n) */
 } rbd_model_info_t;
 
 int rbd_abi_version(void);

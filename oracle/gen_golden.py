@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference")
 
 from RBDReference import RBDReference as RefRBD  # noqa: E402  (the real reference)
-from rbdreference_amd.robot import BUILTIN_ROBOTS, random_tree  # noqa: E402
+from rbdreference_amd.robot import BUILTIN_ROBOTS, FloatingBaseRobot, floating_quadruped_like, random_tree  # noqa: E402
 
 N_SAMPLES = 16
 
@@ -104,6 +104,44 @@ def run_reference(robot, q, qd, qdd):
     return {k: np.stack(vv) for k, vv in out.items()}
 
 
+def fb_robots():
+    """Floating-base fixtures: the reference's floating-base branches of rnea / minv /
+    forward_dynamics on duck-typed robots -- a trunk with four legs, and a 6-body tree with dense frames."""
+    return [("fb_quadruped_like", floating_quadruped_like(), 301),
+            ("fb_random_tree_n6", FloatingBaseRobot(random_tree([-1, 0, 1, 0, 3, 3], seed=5, name="t6"), "fb_random_tree_n6"), 302)]
+
+
+def run_reference_fb(robot, q, qd, qdd):
+    """Only what the reference can do with a floating base; where it raises, the fixture records the
+    exception and the line (documentation, not a test vector)."""
+    import traceback
+    ref = RefRBD(robot)
+    out = {k: [] for k in "fpass_v fpass_a fpass_f c f_acc c_noqdd mb_Minv mb_F mb_U mb_Dinv Minv_dense Minv_upper fd_qdd".split()}
+    for s in range(q.shape[0]):
+        qs, qds, qdds = q[s].copy(), qd[s].copy(), qdd[s].copy()
+        v, a, f = ref.rnea_fpass(qs, qds, qdds)
+        out["fpass_v"].append(v.copy()); out["fpass_a"].append(a.copy()); out["fpass_f"].append(f.copy())
+        c, f_acc = ref.rnea_bpass(qs, f.copy())
+        out["c"].append(c.copy()); out["f_acc"].append(f_acc.copy())
+        out["c_noqdd"].append(ref.rnea(qs, qds)[0].copy())
+        Mb, F, U, D = ref.minv_bpass(qs)
+        out["mb_Minv"].append(Mb.copy()); out["mb_F"].append(F.copy()); out["mb_U"].append(U.copy()); out["mb_Dinv"].append(D.copy())
+        out["Minv_dense"].append(ref.minv(qs, True).copy()); out["Minv_upper"].append(ref.minv(qs, False).copy())
+        out["fd_qdd"].append(np.asarray(ref.forward_dynamics(qs, qds, qdds)).copy())
+    data = {k: np.stack(vv) for k, vv in out.items()}
+    raises = []
+    for nm, fn in (("rnea_grad", lambda: ref.rnea_grad(q[0], qd[0], qdd[0])), ("crba", lambda: ref.crba(q[0])),
+                   ("aba", lambda: ref.aba(q[0], qd[0], qdd[0]))):
+        try:
+            fn()
+            raises.append(f"{nm}: ran")
+        except Exception as e:      # noqa: BLE001  (recording whatever the reference does)
+            ln = traceback.extract_tb(sys.exc_info()[2])[-1].lineno
+            raises.append(f"{nm}: {type(e).__name__} at RBDReference.py:{ln}")
+    data["reference_raises"] = np.array(raises)
+    return data
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -120,6 +158,17 @@ def main():
     robots.append(("random_forest_n8", random_tree([-1, -1, 0, 1, 2, 0, 3, 5], seed=33,
                                                     name="random_forest_n8"), 204))
     only = set(sys.argv[1:])
+    for nm, robot, seed in fb_robots():
+        if only and nm not in only:
+            continue
+        n = robot.get_num_vel()
+        q, qd, qdd = sample_inputs(n, seed, 8)
+        data = run_reference_fb(robot, q, qd, qdd)
+        data.update(q=q, qd=qd, qdd=qdd, seed=np.int64(seed),
+                    parent=np.array([robot.get_parent_id(i) for i in range(robot.get_num_bodies())], dtype=np.int64))
+        path = os.path.join(outdir, f"golden_{nm}.npz")
+        np.savez_compressed(path, **data)
+        print(f"{path}: nb={robot.get_num_bodies()} n={n} samples=8 size={os.path.getsize(path)} B  {list(data['reference_raises'])}")
     if only:
         robots = [r for r in robots if r[0] in only]
     for nm, robot, seed in robots:

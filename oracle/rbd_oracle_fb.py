@@ -1,0 +1,230 @@
+"""CPU oracle for the FLOATING-BASE branches of rnea / minv / forward_dynamics -- TEST INFRASTRUCTURE.
+
+Same role and rules as ``oracle/rbd_oracle.py`` (only tests, ``smoke()`` and the bench's CPU-baseline
+leg may import it).  A from-scratch numpy restatement (float64, batch axis first) of what
+``/root/reference/RBDReference.py`` does when ``robot.floating_base`` is set: body 0 is attached by a
+6-DoF joint with ``S = eye(6)`` and owns indices 0..5, body ``i >= 1`` owns index ``i + 5``
+(``:585-593, :652-691, :761-779``).
+
+Pinning: ``oracle/gen_golden.py`` runs the real reference on ``FloatingBaseRobot`` objects
+(``tests/golden/golden_fb_*.npz``); ``tests/test_oracle_golden.py`` holds this file to them at 1e-12.
+Only ``rnea``, ``minv`` and ``forward_dynamics`` exist for floating bases: the reference itself raises in
+``rnea_grad`` (``:1168``: indexes body ``ii`` of a ``(6, n, NB)`` array with ``ii`` up to 5), ``crba``
+(``:1063``) and ``aba`` (``:900``) on such a robot -- recorded in DESIGN.md, nothing to restate.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from . import rbd_oracle as fx
+
+__all__ = ["FbModel", "model_from_robot", "Xmats", "rnea_fpass", "rnea_bpass", "rnea", "minv_bpass",
+           "minv_fpass", "minv", "forward_dynamics", "joint_space_inertia"]
+
+
+@dataclass
+class FbModel:
+    nb: int                 # bodies
+    n: int                  # velocities = nb + 5
+    parent: List[int]
+    subtree: List[List[int]]
+    S: np.ndarray           # [nb, 6]   (row 0 unused: the base has S = eye(6))
+    I: np.ndarray           # [nb, 6, 6]
+    joints: fx.OracleModel  # X(q) fits of bodies 1.. (index 0 is a dummy identity joint)
+    base_X: object          # callable q6 -> 6x6 (get_Xmat_Func_by_id(0))
+
+
+def model_from_robot(robot) -> FbModel:
+    assert getattr(robot, "floating_base", False)
+    nb = int(robot.get_num_bodies())
+    assert int(robot.get_num_vel()) == nb + 5
+    assert np.array_equal(np.asarray(robot.get_S_by_id(0)), np.eye(6))
+    assert list(robot.get_joint_index_q(0)) == [0, 1, 2, 3, 4, 5] and list(robot.get_joint_index_v(0)) == [0, 1, 2, 3, 4, 5]
+
+    class _View:       # bodies 1.. seen as a fixed-base robot so that the X(q) sampling of rbd_oracle applies
+        floating_base = False
+
+        def __getattr__(self, k):
+            return getattr(robot, k)
+
+        def get_num_vel(self):
+            return nb
+
+        def get_S_by_id(self, i):
+            return np.array([0, 0, 1.0, 0, 0, 0]) if i == 0 else robot.get_S_by_id(i)
+
+        def get_Xmat_Func_by_id(self, i):
+            if i == 0:
+                from math import cos, sin
+                return lambda q: np.block([[np.array([[cos(q), sin(q), 0], [-sin(q), cos(q), 0], [0, 0, 1.0]]), np.zeros((3, 3))],
+                                           [np.zeros((3, 3)), np.array([[cos(q), sin(q), 0], [-sin(q), cos(q), 0], [0, 0, 1.0]])]])
+            return robot.get_Xmat_Func_by_id(i)
+
+        def get_joint_index_q(self, i):
+            return i
+
+        get_joint_index_v = get_joint_index_q
+    for i in range(1, nb):
+        assert int(robot.get_joint_index_q(i)) == i + 5 and int(robot.get_joint_index_v(i)) == i + 5
+    jm = fx.model_from_robot(_View())
+    return FbModel(nb, nb + 5, jm.parent, jm.subtree, jm.S, jm.I, jm, robot.get_Xmat_Func_by_id(0))
+
+
+def Xmats(m: FbModel, q: np.ndarray) -> np.ndarray:
+    """X_i(q) for every body: [B, nb, 6, 6]; body 0 from the base's six coordinates."""
+    B = q.shape[0]
+    qj = np.concatenate([np.zeros((B, 1)), q[:, 6:]], axis=1)
+    X = fx.Xmats(m.joints, qj)
+    X[:, 0] = np.stack([np.asarray(m.base_X(q[b, :6]), dtype=np.float64) for b in range(B)])
+    return X
+
+
+def _batch(x, n):
+    x = np.asarray(x, dtype=np.float64)
+    return (x[None], True) if x.ndim == 1 else (x, False)
+
+
+def rnea_fpass(m: FbModel, q, qd, qdd=None, GRAVITY=-9.81):
+    """RBDReference.py:559-598 with the floating-base lines :585, :591 (vJ = S qd[0:6] = the base twist)."""
+    q, unb = _batch(q, m.n); qd, _ = _batch(qd, m.n)
+    qdd = None if qdd is None else _batch(qdd, m.n)[0]
+    B = q.shape[0]
+    X = Xmats(m, q)
+    v = np.zeros((B, 6, m.nb)); a = np.zeros((B, 6, m.nb)); f = np.zeros((B, 6, m.nb))
+    g = np.zeros(6); g[5] = -GRAVITY
+    for i in range(m.nb):
+        p = m.parent[i]
+        if p == -1:
+            a[:, :, i] = X[:, i] @ g                                                    # :578
+        else:
+            v[:, :, i] = np.einsum("bij,bj->bi", X[:, i], v[:, :, p])                 # :580
+            a[:, :, i] = np.einsum("bij,bj->bi", X[:, i], a[:, :, p])                 # :581
+        if i == 0:
+            vJ = qd[:, 0:6]                                                             # :585  (S = eye(6))
+        else:
+            vJ = m.S[i][None, :] * qd[:, i + 5][:, None]                                # :586
+        v[:, :, i] += vJ                                                                # :587
+        a[:, :, i] += np.einsum("bij,bj->bi", fx._crm(v[:, :, i]), vJ)                 # :588  mxS(vJ, v) = crm(v) vJ
+        if qdd is not None:
+            a[:, :, i] += qdd[:, 0:6] if i == 0 else m.S[i][None, :] * qdd[:, i + 5][:, None]   # :589-593
+        Iv = np.einsum("ij,bj->bi", m.I[i], v[:, :, i])
+        f[:, :, i] = np.einsum("ij,bj->bi", m.I[i], a[:, :, i]) + fx._fxv(v[:, :, i], Iv)       # :595-596
+    return (v[0], a[0], f[0]) if unb else (v, a, f)
+
+
+def rnea_bpass(m: FbModel, q, f):
+    """RBDReference.py:600-621: c[inds_f] = S^T f (the base's six entries are f_0 itself), f accumulated."""
+    q, unb = _batch(q, m.n)
+    f = np.array(f, dtype=np.float64, copy=True)
+    if unb:
+        f = f[None]
+    B = q.shape[0]
+    X = Xmats(m, q)
+    c = np.zeros((B, m.n))
+    for i in range(m.nb - 1, -1, -1):
+        if i == 0:
+            c[:, 0:6] = f[:, :, 0]                                                      # :612 with S = eye(6)
+        else:
+            c[:, i + 5] = np.einsum("j,bj->b", m.S[i], f[:, :, i])
+        p = m.parent[i]
+        if p != -1:
+            f[:, :, p] += np.einsum("bji,bj->bi", X[:, i], f[:, :, i])                 # :618-619
+    return (c[0], f[0]) if unb else (c, f)
+
+
+def rnea(m: FbModel, q, qd, qdd=None, GRAVITY=-9.81):
+    v, a, f = rnea_fpass(m, q, qd, qdd, GRAVITY)
+    c, f = rnea_bpass(m, q, f)
+    return c, v, a, f
+
+
+def minv_bpass(m: FbModel, q):
+    """RBDReference.py:630-735, floating-base branches (:652-691): matrix index = body + 5, the base
+    handled as one 6 x 6 block (fb_Dinv = inv(S^T IA_0 S), :679-683)."""
+    q, unb = _batch(q, m.n)
+    B = q.shape[0]; n = m.n
+    X = Xmats(m, q)
+    Minv = np.zeros((B, n, n)); F = np.zeros((B, n, 6, n)); U = np.zeros((B, n, 6)); Dinv = np.zeros((B, n))
+    IA = np.broadcast_to(m.I[None], (B, m.nb, 6, 6)).copy()                             # :662
+    for i in range(m.nb - 1, -1, -1):
+        sub = [j + 5 for j in m.subtree[i]]                                             # :668-671
+        p = m.parent[i]
+        if p == -1:                                                                     # :676-691 (base)
+            U[:, 0:6, :] = IA[:, 0]                                                     # :680  IA S, S = eye(6)
+            fb = np.linalg.inv(IA[:, 0])                                                # :681-683
+            Minv[:, 0:6, 0:6] = Minv[:, 0:1, 0:1] + fb                                  # :685  (Minv[0, 0] is 0 here)
+            Minv[:, 0:6, sub] -= fb @ F[:, 5][:, :, sub]                                # :686-691: the `[-1]` selects F[5], the base's F slot
+        else:
+            mi = i + 5; mp = p + 5
+            U[:, mi] = np.einsum("bij,j->bi", IA[:, i], m.S[i])                         # :697
+            Dinv[:, mi] = np.einsum("j,bj->b", m.S[i], U[:, mi])                        # :698 (holds D)
+            Minv[:, mi, mi] = 1.0 / Dinv[:, mi]                                         # :700
+            Minv[:, mi, sub] -= (1.0 / Dinv[:, mi])[:, None] * np.einsum("j,bjs->bs", m.S[i], F[:, mi][:, :, sub])   # :702-708
+            for s in sub:                                                               # :720-726
+                F[:, mi, :, s] += U[:, mi] * Minv[:, mi, s][:, None]
+                F[:, mp, :, s] += np.einsum("bji,bj->bi", X[:, i], F[:, mi, :, s])
+            Ia = IA[:, i] - np.einsum("bi,bj->bij", U[:, mi], U[:, mi]) / Dinv[:, mi][:, None, None]   # :728-731
+            IA[:, p] += np.einsum("bji,bjk,bkl->bil", X[:, i], Ia, X[:, i])             # :732-733
+    return (Minv[0], F[0], U[0], Dinv[0]) if unb else (Minv, F, U, Dinv)
+
+
+def minv_fpass(m: FbModel, q, Minv, F, U, Dinv):
+    """RBDReference.py:737-783: F is indexed by BODY id here (:772, :774, :779), Minv rows by body + 5."""
+    q, unb = _batch(q, m.n)
+    Minv = np.array(Minv, dtype=np.float64, copy=True); F = np.array(F, dtype=np.float64, copy=True)
+    U = np.asarray(U, dtype=np.float64); Dinv = np.asarray(Dinv, dtype=np.float64)
+    if unb:
+        Minv, F, U, Dinv = Minv[None], F[None], U[None], Dinv[None]
+    X = Xmats(m, q)
+    for i in range(m.nb):
+        p = m.parent[i]
+        if p == -1:
+            F[:, 0] = Minv[:, 0:6, :]                                                   # :779  S @ Minv[0:6, 0:]
+        else:
+            mi = i + 5
+            UX = np.einsum("bj,bjk->bk", U[:, mi], X[:, i])
+            Minv[:, mi, :] -= (1.0 / Dinv[:, mi])[:, None] * np.einsum("bk,bkc->bc", UX, F[:, p])       # :771-773
+            F[:, i] = X[:, i] @ F[:, p] + np.einsum("j,bc->bjc", m.S[i], Minv[:, mi, :])                 # :774-776
+    return Minv[0] if unb else Minv
+
+
+def minv(m: FbModel, q, output_dense=True):
+    """RBDReference.py:785-806.  With a floating base the forward pass completes EVERY row (the base rows
+    are dense from the start), so the matrix is the full inverse either way; the reference's mirror loop
+    (:799-804, over range(NB) only) touches the already symmetric top-left block."""
+    Mb, F, U, D = minv_bpass(m, q)
+    Mi = minv_fpass(m, q, Mb, F, U, D)
+    if output_dense:
+        nb = m.nb
+        Mi = np.array(Mi, copy=True)
+        M2 = Mi if Mi.ndim == 3 else Mi[None]
+        for col in range(nb):
+            for row in range(nb):
+                if col < row:
+                    M2[:, row, col] = M2[:, col, row]
+    return Mi
+
+
+def forward_dynamics(m: FbModel, q, qd, u, GRAVITY=-9.81):
+    """RBDReference.py:1371-1374: minv(q) @ (u - rnea(q, qd)[0])."""
+    c = rnea(m, q, qd, None, GRAVITY)[0]
+    Mi = minv(m, q)
+    u = np.asarray(u, dtype=np.float64)
+    return np.einsum("...ij,...j->...i", Mi, u - c)
+
+
+def joint_space_inertia(m: FbModel, q):
+    """H from rnea columns (the reference's crba raises for floating bases): H[:, k] = rnea(q, 0, e_k) - rnea(q, 0, 0),
+    gravity off.  Witness for Minv H = I."""
+    q, unb = _batch(q, m.n)
+    B = q.shape[0]
+    z = np.zeros((B, m.n))
+    c0 = rnea(m, q, z, z, GRAVITY=0.0)[0]
+    H = np.zeros((B, m.n, m.n))
+    for k in range(m.n):
+        e = np.zeros((B, m.n)); e[:, k] = 1.0
+        H[:, :, k] = rnea(m, q, z, e, GRAVITY=0.0)[0] - c0
+    return H[0] if unb else H

@@ -4,12 +4,13 @@
     rbd = RBDReference(iiwa_like())
     c, dc_du = rbd.rnea_grad(q, qd, qdd, return_c=True)      # q, qd, qdd: [B, 7] cuda tensors
 """
-from .robot import (BUILTIN_ROBOTS, Link, Robot, atlas_like, builtin_robot, iiwa_like,
-                    quadruped_like, random_tree)
+from .robot import (BUILTIN_ROBOTS, FloatingBaseRobot, Link, Robot, atlas_like, builtin_robot,
+                    floating_quadruped_like, iiwa_like, quadruped_like, random_tree)
 from .packer import PackedModel, pack_robot
 from .urdf import load_urdf, loads_urdf, to_urdf
 
-__all__ = ["RBDReference", "Robot", "Link", "iiwa_like", "quadruped_like", "atlas_like",
+__all__ = ["RBDReference", "Robot", "FloatingBaseRobot", "floating_quadruped_like", "Link", "iiwa_like",
+           "quadruped_like", "atlas_like",
            "random_tree", "builtin_robot", "BUILTIN_ROBOTS", "pack_robot", "PackedModel",
            "load_urdf", "loads_urdf", "to_urdf"]
 

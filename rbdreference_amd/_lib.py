@@ -45,7 +45,7 @@ class RbdModelInfo(Structure):
     _fields_ = [("abi_version", c_int32), ("n", c_int32), ("max_depth", c_int32),
                 ("hash", c_uint64), ("name", c_char * 64),
                 ("parent", c_int32 * RBD_MAX_BODIES), ("joint_type", c_int32 * RBD_MAX_BODIES),
-                ("joint_axis", c_int32 * RBD_MAX_BODIES)]
+                ("joint_axis", c_int32 * RBD_MAX_BODIES), ("floating_base", c_int32), ("nv", c_int32)]
 
 
 class RbdError(RuntimeError):
@@ -133,7 +133,8 @@ class RbdLibrary:
         info = RbdModelInfo()
         self.check(self.lib.rbd_model_info(ctypes.byref(info)))
         if info.n != model.n or f"{info.hash:016x}" != model.hash or \
-                list(info.parent[:model.n]) != list(model.parent):
+                list(info.parent[:model.n]) != list(model.parent) or info.nv != model.nv or \
+                bool(info.floating_base) != bool(model.floating):
             raise RuntimeError(f"{path}: compiled-in model does not match robot {model.name!r}")
         self.info = info
 

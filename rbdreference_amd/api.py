@@ -26,7 +26,8 @@ class RBDReference:
         self.robot = robotObj                     # RBDReference.py:7
         self.model: PackedModel = pack_robot(robotObj)
         self._lib = RbdLibrary(self.model, build=build)
-        self.n = self.model.n
+        self.n = self.model.n            # bodies
+        self.nv = self.model.nv          # columns of q, qd, qdd, c: n, or n + 5 with a floating base
 
     # ------------------------------------------------------------------------------------
     def _prep(self, *arrs):
@@ -61,8 +62,8 @@ class RBDReference:
             u = t.dim() == 1
             if u:
                 t = t[None, :]
-            if t.dim() != 2 or t.shape[1] != self.n:
-                raise ValueError(f"expected shape [{self.n}] or [B, {self.n}], got {tuple(x.shape) if hasattr(x, 'shape') else len(x)}")
+            if t.dim() != 2 or t.shape[1] != self.nv:
+                raise ValueError(f"expected shape [{self.nv}] or [B, {self.nv}], got {tuple(x.shape) if hasattr(x, 'shape') else len(x)}")
             if unb is None:
                 unb, B = u, t.shape[0]
             elif u != unb or t.shape[0] != B:
@@ -91,7 +92,7 @@ class RBDReference:
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         with torch.cuda.device(dev):
-            c = torch.empty((B, self.n), device=dev, dtype=dt)
+            c = torch.empty((B, self.nv), device=dev, dtype=dt)
             if outputs == "cvaf":
                 v = torch.empty((B, 6, self.n), device=dev, dtype=dt)
                 a = torch.empty_like(v)
@@ -328,7 +329,7 @@ class RBDReference:
         B = q.shape[0]
         esz = 4 if dt == torch.float32 else 8
         with torch.cuda.device(dev):
-            M = torch.empty((B, self.n, self.n), device=dev, dtype=dt)
+            M = torch.empty((B, self.nv, self.nv), device=dev, dtype=dt)
             wsb = int(self._lib.lib.rbd_minv_workspace_bytes(B, esz))
             ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
             st = torch.cuda.current_stream(dev).cuda_stream
@@ -365,8 +366,14 @@ class RBDReference:
         B = q.shape[0]
         esz = 4 if dt == torch.float32 else 8
         with torch.cuda.device(dev):
-            qdd = torch.empty((B, self.n), device=dev, dtype=dt)
+            qdd = torch.empty((B, self.nv), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
+            if not want_grad and self.model.floating:   # rnea (bias force) + minv + one product: scratch for c and Minv
+                wsb = int(self._lib.lib.rbd_fd_workspace_bytes(B, esz))
+                ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
+                self._lib.check(self._fn("rbd_forward_dynamics", dt)(
+                    self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), ws.data_ptr(), wsb, st))
+                return qdd, None, unb, is_np
             if not want_grad:        # one articulated-body launch, no scratch
                 self._lib.check(self._fn("rbd_forward_dynamics", dt)(
                     self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), None, 0, st))

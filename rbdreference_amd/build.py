@@ -65,6 +65,8 @@ def _sources_digest(m: PackedModel, flags) -> str:
 
 TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64",
                      "FD_F32", "FD_F64", "PASS_F32", "PASS_F64"]
+# floating-base robots: COMMON from rbd_kernels.hip + the two units of rbd_fb_kernels.hip
+FB_TRANSLATION_UNITS = ["COMMON", "FB_F32", "FB_F64"]
 class _PrioritySlots:
     """At most `n` hipcc processes at a time; when one finishes, the waiting job with the highest
     cost estimate goes next (longest-first keeps the one 3-minute unit of a 30-body robot from
@@ -168,7 +170,10 @@ def _build_locked(m, out, flags, digest, force, verbose) -> str:
     with open(hdr_tmp, "w") as f:
         f.write(emit_header(m))
     os.replace(hdr_tmp, hdr)                  # same content from every writer; rename is atomic
-    src = os.path.join(CSRC, "rbd_kernels.hip")
+    units = FB_TRANSLATION_UNITS if m.floating else TRANSLATION_UNITS
+
+    def src_of(tu):
+        return os.path.join(CSRC, "rbd_fb_kernels.hip" if tu.startswith("FB_") else "rbd_kernels.hip")
 
     cache_dir = os.path.join(BUILD_DIR, "objcache")
     os.makedirs(cache_dir, exist_ok=True)
@@ -178,6 +183,7 @@ def _build_locked(m, out, flags, digest, force, verbose) -> str:
         # recompiles the units that include it (the optimiser, not the front end, is the cost).
         import hashlib
         base = [hipcc_path(), *[f for f in flags if f != "-shared"], "-DRBD_TU_SPLIT=1", f"-DRBD_TU_{tu}=1", "-include", hdr]
+        src = src_of(tu)
         cost = _TU_COST.get(tu, 50) * m.n * m.n
         pre = _run([*base, "-E", "-P", src, "-o", "-"], f"{m.name} {tu} (preprocess)", cost + 1e9)   # cheap: first
         key = hashlib.sha256((pre.stdout + "\0" + " ".join(flags)).encode()).hexdigest()[:32]
@@ -200,8 +206,8 @@ def _build_locked(m, out, flags, digest, force, verbose) -> str:
         os.replace(tmp, obj)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(TRANSLATION_UNITS)) as ex:
-        objs = list(ex.map(compile_tu, TRANSLATION_UNITS))
+    with ThreadPoolExecutor(max_workers=len(units)) as ex:
+        objs = list(ex.map(compile_tu, units))
     link_tmp = f"{out}.{uniq}.tmp"
     _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", link_tmp],
          f"{m.name} link", 2e9)

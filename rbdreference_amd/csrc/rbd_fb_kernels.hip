@@ -1,0 +1,122 @@
+// rbd_fb_kernels.hip -- the translation units of a FLOATING-BASE robot's library (besides COMMON, which
+// comes from rbd_kernels.hip): rbd_fb.h's kernels behind the same C-ABI (include/rbd_hip.h).
+//
+// A floating-base library exports every symbol of the header; the entry points the reference itself
+// cannot serve for a floating base (its rnea_grad needs NB >= 6 and is not restated yet, its crba and aba
+// raise: RBDReference.py:1168, :1063, :900) and the per-pass / forward_dynamics_grad entry points return
+// RBD_ERR_UNSUPPORTED with a message.  Shapes: q, qd, qdd, c, u [B, NV]; v, a, f [B, 6, N]; Minv [B, NV, NV].
+// Units: -DRBD_TU_FB_F32 / -DRBD_TU_FB_F64 (rbdreference_amd/build.py).
+#include "rbd_fb.h"
+#include "../../include/rbd_hip.h"
+#include <cstdio>
+#include <cstring>
+
+static_assert(rbdm::FLOATING_BASE, "rbd_fb_kernels.hip is for floating-base robots");
+
+extern "C" __attribute__((visibility("hidden"))) char* rbd_err_buf(void);
+namespace {
+constexpr size_t RBD_ERR_LEN = 512;
+int fail(int code, const char* msg) { std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s", msg); return code; }
+int hip_fail(hipError_t e, const char* where) {
+  std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: %s", where, hipGetErrorString(e));
+  return (int)e > 0 ? (int)e : 1;
+}
+int unsupported(const char* who) {
+  std::snprintf(rbd_err_buf(), RBD_ERR_LEN,
+                "%s: not available for floating-base robots (supported: rbd_rnea, rbd_minv, rbd_forward_dynamics)", who);
+  return RBD_ERR_UNSUPPORTED;
+}
+constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+template <class T>
+int rnea_fb_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !c) return fail(RBD_ERR_ARG, "rbd_rnea: q, qd and c must be non-null");
+  const bool vaf = v || a || f;
+  if (vaf && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea: v, a, f must be all null or all non-null");
+  const int64_t blocks = (B + 63) / 64;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea: B too large");
+  if (qdd) hipLaunchKernelGGL((rnea_fb_kernel<T, true>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+  else hipLaunchKernelGGL((rnea_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_rnea (floating base) launch");
+}
+template <class T>
+int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
+  if (B == 0) return 0;
+  if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  const int64_t blocks = (B + 63) / 64;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
+  hipLaunchKernelGGL((minv_fb_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, dense, Minv);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_minv (floating base) launch");
+}
+template <class T>
+int fd_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, void* workspace, size_t wsb, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !u || !qdd) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: q, qd, u, qdd must be non-null");
+  const size_t off_c = 0, off_m = align16((size_t)B * NV * sizeof(T)), total = off_m + align16((size_t)B * NV * NV * sizeof(T));
+  if (!workspace || wsb < total) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics: workspace missing or smaller than rbd_fd_workspace_bytes()");
+  char* w = reinterpret_cast<char*>(workspace);
+  T* c = reinterpret_cast<T*>(w + off_c);
+  T* Mi = reinterpret_cast<T*>(w + off_m);
+  int rc;
+  if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
+  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream)) != 0) return rc;                                               // :1373
+  const int64_t ab = ((int64_t)B * NV + 255) / 256;
+  if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B too large");
+  hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_forward_dynamics (floating base) launch");
+}
+}  // namespace
+
+extern "C" {
+// kernel names for rbd_kernel_name (COMMON unit)
+__attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f32(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len);
+
+#define RBD_FB_DEFS(SFX, T)                                                                                                 \
+  int rbd_grad_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "(none: floating base)"); return 0; } \
+  int rbd_minv_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "minv_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
+  int rbd_rnea_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {   \
+    return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \
+  }                                                                                                                         \
+  int rbd_minv_##SFX(const T* q, int64_t B, int output_dense, T* Minv, void*, size_t, void* stream) {                       \
+    return minv_fb_launch<T>(q, B, output_dense, Minv, stream);                                                             \
+  }                                                                                                                         \
+  int rbd_forward_dynamics_##SFX(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, void* ws, size_t wsb,   \
+                                 void* stream) {                                                                            \
+    return fd_fb_launch<T>(q, qd, u, gravity, B, qdd, ws, wsb, stream);                                                     \
+  }                                                                                                                         \
+  int rbd_rnea_fpass_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_fpass"); } \
+  int rbd_rnea_bpass_##SFX(const T*, T*, int64_t, T*, void*) { return unsupported("rbd_rnea_bpass"); }                      \
+  int rbd_rnea_grad_##SFX(const T*, const T*, const T*, T, int, int64_t, T*, T*, void*) { return unsupported("rbd_rnea_grad"); } \
+  int rbd_rnea_with_grad_##SFX(const T*, const T*, const T*, T, int, int64_t, T*, T*, T*, T*, T*, void*) { return unsupported("rbd_rnea_with_grad"); } \
+  int rbd_rnea_grad_fpass_dq_##SFX(const T*, const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_grad_fpass_dq"); } \
+  int rbd_rnea_grad_fpass_dqd_##SFX(const T*, const T*, const T*, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_grad_fpass_dqd"); } \
+  int rbd_rnea_grad_bpass_dq_##SFX(const T*, const T*, T*, int64_t, T*, void*) { return unsupported("rbd_rnea_grad_bpass_dq"); } \
+  int rbd_rnea_grad_bpass_dqd_##SFX(const T*, T*, int, int64_t, T*, void*) { return unsupported("rbd_rnea_grad_bpass_dqd"); } \
+  int rbd_minv_bpass_##SFX(const T*, int64_t, T*, T*, T*, T*, void*) { return unsupported("rbd_minv_bpass"); }              \
+  int rbd_minv_fpass_##SFX(const T*, int64_t, T*, T*, const T*, const T*, void*) { return unsupported("rbd_minv_fpass"); }  \
+  int rbd_crba_##SFX(const T*, int64_t, T*, void*) { return unsupported("rbd_crba"); }                                      \
+  int rbd_aba_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*) { return unsupported("rbd_aba"); }                 \
+  int rbd_forward_dynamics_grad_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, void*, size_t, void*) {             \
+    return unsupported("rbd_forward_dynamics_grad");                                                                        \
+  }
+
+#ifdef RBD_TU_FB_F32
+RBD_FB_DEFS(f32, float)
+#endif
+#ifdef RBD_TU_FB_F64
+RBD_FB_DEFS(f64, double)
+#endif
+}  // extern "C"

@@ -1725,6 +1725,8 @@ int rbd_model_info(rbd_model_info_t* out) {
   out->n = rbdm::N;
   out->max_depth = rbdm::MAXDEPTH;
   out->hash = RBD_MODEL_HASH;
+  out->floating_base = rbdm::FLOATING_BASE ? 1 : 0;
+  out->nv = rbdm::NV;
   std::snprintf(out->name, sizeof(out->name), "%s", RBD_MODEL_NAME);
   for (int i = 0; i < rbdm::N && i < RBD_MAX_BODIES; ++i) {
     out->parent[i] = rbdm::PARENT[i];
@@ -1735,10 +1737,15 @@ int rbd_model_info(rbd_model_info_t* out) {
 }
 size_t rbd_minv_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
+  if (rbdm::FLOATING_BASE) return 0;
   return (size_t)B * rbdk::MINV_WS_PER_CFG * (size_t)elem_size;
 }
 size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0) return 0;
+  if (rbdm::FLOATING_BASE) {      // c [B, NV] + Minv [B, NV, NV]  (rbd_fb_kernels.hip)
+    if (elem_size != 4 && elem_size != 8) return 0;
+    return align16((size_t)B * rbdm::NV * elem_size) + align16((size_t)B * rbdm::NV * rbdm::NV * elem_size);
+  }
   if (elem_size == 4) return FdWorkspace<float>(B).total;
   if (elem_size == 8) return FdWorkspace<double>(B).total;
   return 0;

@@ -24,7 +24,7 @@ import numpy as np
 
 __all__ = ["PackedModel", "pack_robot", "emit_header", "safe_name", "ABI_VERSION"]
 
-ABI_VERSION = 1
+ABI_VERSION = 2       # 2: rbd_model_info_t gained floating_base / nv; floating-base libraries
 
 
 @dataclass
@@ -39,6 +39,12 @@ class PackedModel:
     damping: np.ndarray       # [n] float64
     depth: List[int]          # 0 for children of the base
     hash: str                 # 16 hex digits over everything above (not the name)
+    floating: bool = False    # body 0 is attached by a 6-DoF joint (jtype[0] == 2), S = eye(6)
+
+    @property
+    def nv(self) -> int:
+        """Velocities (= columns of q, qd, qdd): n for fixed-base robots, n + 5 with a floating base."""
+        return self.n + 5 if self.floating else self.n
 
     @property
     def max_depth(self) -> int:
@@ -69,23 +75,51 @@ def _joint_X(jtype: int, k: int, q: float) -> np.ndarray:
     return X
 
 
+def _pack_floating_base_joint(robot, n):
+    """Validate body 0 of a floating-base robot: S = eye(6), indices 0..5, and the world -> base
+    transform of robot.floating_base_X (Px, Py, Pz, Rx, Ry, Rz; RBDReference.py:634-637)."""
+    from .robot import floating_base_X
+    if int(robot.get_parent_id(0)) != -1:
+        raise ValueError("floating base: body 0 must be the base")
+    if not np.array_equal(np.asarray(robot.get_S_by_id(0), dtype=np.float64), np.eye(6)):
+        raise ValueError("floating base: S of body 0 must be eye(6) (RBDReference.py:679)")
+    for g in ("get_joint_index_q", "get_joint_index_v", "get_joint_index_f"):
+        if list(getattr(robot, g)(0)) != [0, 1, 2, 3, 4, 5]:
+            raise ValueError(f"floating base: {g}(0) must be [0..5]")
+    f = robot.get_Xmat_Func_by_id(0)
+    for qq in (np.zeros(6), np.array([0.3, -0.2, 0.5, 0.4, -1.1, 2.0]), np.array([-1.0, 0.7, 0.1, -2.5, 0.9, -0.3])):
+        if not np.allclose(np.asarray(f(qq), dtype=np.float64), floating_base_X(qq), rtol=0, atol=1e-12):
+            raise ValueError("floating base: Xmat of body 0 is not plux(Rz Ry Rx, p) of (px,py,pz,rx,ry,rz) "
+                             "(unsupported base parametrisation)")
+
+
 def pack_robot(robot, name: str | None = None) -> PackedModel:
-    if getattr(robot, "floating_base", False):
-        raise NotImplementedError("floating-base robots are out of scope (SURVEY.md §2 row 16)")
+    floating = bool(getattr(robot, "floating_base", False))
     n = int(robot.get_num_bodies())
-    if int(robot.get_num_vel()) != n:
-        raise ValueError("only 1-DoF joints are supported (num_vel != num_bodies)")
+    if int(robot.get_num_vel()) != (n + 5 if floating else n):
+        raise ValueError("only 1-DoF joints (and one 6-DoF floating base) are supported (num_vel mismatch)")
     if not (1 <= n <= 64):
         raise ValueError(f"n = {n}: supported range is 1..64")
+    if floating:
+        _pack_floating_base_joint(robot, n)
+    off = 5 if floating else 0
     parent, jtype, axis = [], [], []
     Xt = np.zeros((n, 6, 6)); Im = np.zeros((n, 6, 6)); damp = np.zeros(n)
     for i in range(n):
         p = int(robot.get_parent_id(i))
         if not (-1 <= p < i):
             raise ValueError(f"body {i}: parent {p} must precede it")
+        if floating and i > 0 and p == -1:
+            raise ValueError(f"body {i}: with a floating base every other body must descend from body 0")
+        if floating and i == 0:
+            parent.append(-1); jtype.append(2); axis.append(0)
+            Xt[0] = np.eye(6)
+            I = np.asarray(robot.get_Imat_by_id(0), dtype=np.float64).reshape(6, 6)
+            Im[0] = 0.5 * (I + I.T)
+            continue
         for g in ("get_joint_index_q", "get_joint_index_v", "get_joint_index_f"):
-            if int(getattr(robot, g)(i)) != i:
-                raise ValueError(f"body {i}: {g} != body id (fixed-base 1-DoF layout expected)")
+            if int(getattr(robot, g)(i)) != i + off:
+                raise ValueError(f"body {i}: {g} != body id{' + 5' if floating else ''} (1-DoF layout expected)")
         parent.append(p)
         S = np.asarray(robot.get_S_by_id(i), dtype=np.float64).reshape(-1)
         nz = np.flatnonzero(S)
@@ -120,13 +154,13 @@ def pack_robot(robot, name: str | None = None) -> PackedModel:
         if st != mine:
             raise ValueError(f"body {i}: get_subtree_by_id disagrees with get_parent_id")
     h = hashlib.sha256()
-    h.update(struct.pack("<ii", ABI_VERSION, n))
+    h.update(struct.pack("<iii", ABI_VERSION, n, int(floating)))
     h.update(np.asarray(parent, dtype=np.int32).tobytes())
     h.update(np.asarray(jtype, dtype=np.int32).tobytes())
     h.update(np.asarray(axis, dtype=np.int32).tobytes())
     h.update(Xt.tobytes()); h.update(Im.tobytes()); h.update(damp.tobytes())
     return PackedModel(name or getattr(robot, "name", "robot"), n, parent, jtype, axis, Xt, Im,
-                       damp, depth, h.hexdigest()[:16])
+                       damp, depth, h.hexdigest()[:16], floating)
 
 
 def _is_anc_or_self(parent, i, j) -> bool:
@@ -169,10 +203,12 @@ def emit_header(m: PackedModel) -> str:
     L.append(f"#define RBD_ABI_VERSION {ABI_VERSION}")
     L.append("namespace rbdm {")
     L.append(f"constexpr int N = {n};")
+    L.append(f"constexpr bool FLOATING_BASE = {'true' if m.floating else 'false'};   // body 0: 6-DoF joint, S = eye(6)")
+    L.append(f"constexpr int NV = {m.nv};                 // velocities: N, or N + 5 with a floating base")
     L.append(f"constexpr int MAXDEPTH = {m.max_depth};")
     L.append(f"constexpr int PARENT[N] = {_carr(m.parent)};")
     L.append(f"constexpr int DEPTH[N] = {_carr(m.depth)};")
-    L.append(f"constexpr int JTYPE[N] = {_carr(m.jtype)};   // 0 revolute, 1 prismatic")
+    L.append(f"constexpr int JTYPE[N] = {_carr(m.jtype)};   // 0 revolute, 1 prismatic, 2 floating base")
     L.append(f"constexpr int AXIS[N] = {_carr(m.axis)};")
     L.append("constexpr double XT[N][36] = {")
     for i in range(n):

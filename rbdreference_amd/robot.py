@@ -33,8 +33,8 @@ from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 
-__all__ = ["Link", "Robot", "iiwa_like", "quadruped_like", "atlas_like", "random_tree",
-           "BUILTIN_ROBOTS", "builtin_robot"]
+__all__ = ["Link", "Robot", "FloatingBaseRobot", "floating_base_X", "iiwa_like", "quadruped_like",
+           "atlas_like", "random_tree", "floating_quadruped_like", "BUILTIN_ROBOTS", "builtin_robot"]
 
 
 def _skew(r: Sequence[float]) -> np.ndarray:
@@ -310,6 +310,91 @@ def random_tree(parent: Sequence[int], seed: int = 0, prismatic_every: int = 0,
                       (Ic[0, 0], Ic[1, 1], Ic[2, 2], Ic[0, 1], Ic[0, 2], Ic[1, 2]),
                       float(rng.uniform(0.0, 1.0)), jt))
     return Robot(name or f"random_tree_n{len(L)}_s{seed}", L)
+
+
+def floating_base_X(q6: Sequence[float]) -> np.ndarray:
+    """World -> base motion transform of the 6-DoF base joint, ``q6 = (px, py, pz, rx, ry, rz)``: the
+    six-joint chain Px, Py, Pz, Rx, Ry, Rz the reference describes (``RBDReference.py:634-637``), i.e.
+    ``plux(Rz(rz) Ry(ry) Rx(rx), p)`` with the coordinate-transform rotations used for every joint."""
+    q6 = np.asarray(q6, dtype=np.float64).reshape(6)
+    E = _rot_axis(2, q6[5]) @ _rot_axis(1, q6[4]) @ _rot_axis(0, q6[3])
+    return plux(E, q6[:3])
+
+
+class FloatingBaseRobot:
+    """Floating-base robot with the getter surface the reference's floating-base branches read
+    (``RBDReference.py:585-593, 652-691, 761-779``): body 0 is the base, attached to the world by a
+    6-DoF joint with ``S = eye(6)``; bodies 1.. hang off it with 1-DoF joints.
+
+    Layout (what those branches assume): ``NB`` bodies, ``n = NB + 5`` velocities; body 0 owns
+    ``q[0:6]``, ``qd[0:6]`` (``qd[0:6]`` is the base TWIST in base coordinates, because ``S`` is the
+    identity), body ``i >= 1`` owns index ``i + 5``.  ``get_Xmat_Func_by_id(0)`` maps the base's six
+    coordinates to the world -> base transform (`floating_base_X`).  What URDFParser does for its
+    floating bases cannot be checked offline: this class pins the REFERENCE's
+    floating-base arithmetic, not URDFParser's parametrisation.
+
+    Built from a fixed-base `Robot` whose body 0 is the only root: that body becomes the base (its own
+    1-DoF joint is dropped, its inertia kept)."""
+
+    floating_base = True
+
+    def __init__(self, inner: Robot, name: str | None = None):
+        n = inner.get_num_bodies()
+        if inner.get_parent_id(0) != -1 or any(inner.get_parent_id(i) == -1 for i in range(1, n)):
+            raise ValueError("FloatingBaseRobot: body 0 must be the only root of the fixed-base robot")
+        self.inner = inner
+        self.name = name or f"fb_{inner.name}"
+        self._n = n
+
+    def get_num_bodies(self) -> int:
+        return self._n
+
+    def get_num_vel(self) -> int:
+        return self._n + 5
+
+    def get_num_pos(self) -> int:
+        return self._n + 5
+
+    def get_parent_id(self, i: int) -> int:
+        return self.inner.get_parent_id(i)
+
+    def get_S_by_id(self, i: int) -> np.ndarray:
+        return np.eye(6) if i == 0 else self.inner.get_S_by_id(i)
+
+    def _idx(self, i: int):
+        return [0, 1, 2, 3, 4, 5] if i == 0 else i + 5
+
+    get_joint_index_q = _idx
+    get_joint_index_v = _idx
+    get_joint_index_f = _idx
+
+    def get_Xmat_Func_by_id(self, i: int):
+        return floating_base_X if i == 0 else self.inner.get_Xmat_Func_by_id(i)
+
+    def get_Imat_by_id(self, i: int) -> np.ndarray:
+        return self.inner.get_Imat_by_id(i)
+
+    def get_Imats_dict_by_id(self) -> Dict[int, np.ndarray]:
+        return self.inner.get_Imats_dict_by_id()
+
+    def get_subtree_by_id(self, i: int) -> List[int]:
+        return self.inner.get_subtree_by_id(i)
+
+    def get_damping_by_id(self, i: int) -> float:
+        return 0.0 if i == 0 else self.inner.get_damping_by_id(i)
+
+    def __repr__(self) -> str:
+        return f"FloatingBaseRobot({self.name!r}, NB={self._n}, n={self._n + 5})"
+
+
+def floating_quadruped_like() -> FloatingBaseRobot:
+    """13 bodies / 18 velocities: a free-floating trunk (HyQ-like mass and inertia) carrying the four
+    3-joint legs of `quadruped_like`."""
+    legs = quadruped_like().links
+    L = [Link("trunk", -1, 2, (0, 0, 0), (0, 0, 0), 53.4, (0.03, 0.0, 0.043), (1.3, 7.0, 7.9, 0.02, -0.2, 0.0), 0.0)]
+    for l in legs:
+        L.append(Link(l.name, 0 if l.parent == -1 else l.parent + 1, l.axis, l.xyz, l.rpy, l.mass, l.com, l.inertia, l.damping))
+    return FloatingBaseRobot(Robot("quadruped_trunk", L), "fb_quadruped_like")
 
 
 BUILTIN_ROBOTS = {"iiwa_like": iiwa_like, "quadruped_like": quadruped_like,

@@ -20,9 +20,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def all_golden_names():
+def _golden_names():
     return sorted(f[len("golden_"):-len(".npz")] for f in os.listdir(GOLDEN_DIR)
                   if f.startswith("golden_") and f.endswith(".npz"))
+
+
+def all_golden_names():
+    """Fixed-base fixtures (every pass of the path)."""
+    return [n for n in _golden_names() if not n.startswith("fb_")]
+
+
+def fb_golden_names():
+    """Floating-base fixtures (rnea, minv, forward_dynamics: what the reference can do with such a robot)."""
+    return [n for n in _golden_names() if n.startswith("fb_")]
 
 
 def load_golden(name):
@@ -31,9 +41,13 @@ def load_golden(name):
 
 def make_robot(name):
     """Rebuild the robot a golden fixture was generated with (see oracle/gen_golden.py)."""
-    from rbdreference_amd.robot import BUILTIN_ROBOTS, random_tree
+    from rbdreference_amd.robot import BUILTIN_ROBOTS, FloatingBaseRobot, floating_quadruped_like, random_tree
     if name in BUILTIN_ROBOTS:
         return BUILTIN_ROBOTS[name]()
+    if name == "fb_quadruped_like":
+        return floating_quadruped_like()
+    if name == "fb_random_tree_n6":
+        return FloatingBaseRobot(random_tree([-1, 0, 1, 0, 3, 3], seed=5, name="t6"), name)
     if name == "random_tree_n9":
         return random_tree([-1, 0, 1, 1, 3, -1, 5, 5, 7], seed=7, name=name)
     if name == "random_chain_n7":

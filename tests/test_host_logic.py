@@ -40,8 +40,8 @@ def test_hash_is_stable_and_sensitive():
 
 
 def test_packer_rejects_unsupported_robots():
-    r = iiwa_like(); r.floating_base = True
-    with pytest.raises(NotImplementedError):
+    r = iiwa_like(); r.floating_base = True              # claims a floating base without its layout (num_vel, S, indices)
+    with pytest.raises(ValueError):
         pack_robot(r)
     r = iiwa_like(); r._S[2] = np.array([0.6, 0.8, 0, 0, 0, 0.0])
     with pytest.raises(ValueError, match="coordinate axis"):
@@ -102,7 +102,8 @@ def test_capi_library_builds_loads_and_exports_every_symbol():
     assert L.rbd_minv_f32(1, 4, 1, None, None, 0, None) == -1
     assert L.rbd_minv_workspace_bytes(10, 2) == 0
     assert L.rbd_rnea_f32(None, None, None, -9.81, 0, None, None, None, None, None) == 0   # B = 0: no-op
-    assert L.rbd_abi_version() == 1
+    from rbdreference_amd.packer import ABI_VERSION
+    assert L.rbd_abi_version() == ABI_VERSION == 2
 
 
 def test_every_prebuilt_library_matches_its_robot():
