@@ -68,15 +68,21 @@ int rbd_model_info(rbd_model_info_t* out);
  *                          robot's batch-parallel kernel at every batch size)
  *   RBD_OPT_MINV_PHASE_A   rbd_minv, two-phase robots: AUTO | LANE (one lane per configuration) |
  *                          IA8 (eight lanes per configuration)
+ *   RBD_OPT_RNEA_KERNEL    rbd_rnea with v, a, f: AUTO | BATCH (one lane per configuration) | GROUPS (one
+ *                          wave per independent root subtree: what AUTO picks for robots with several)
  * rbd_kernel_name writes the name of the kernel (the dominant one of a multi-launch entry point) that
  * `op` would launch for a batch of B rows of elem_size-byte scalars under the current options. */
 #define RBD_OPT_GRAD_KERNEL 0
 #define RBD_OPT_MINV_PHASE_A 1
-#define RBD_OPT_COUNT_ 2
+#define RBD_OPT_RNEA_KERNEL 2
+#define RBD_OPT_COUNT_ 3
 #define RBD_GRAD_KERNEL_AUTO 0
 #define RBD_GRAD_KERNEL_TREE 1
 #define RBD_GRAD_KERNEL_COLS 2
 #define RBD_GRAD_KERNEL_BATCH 3
+#define RBD_RNEA_KERNEL_AUTO 0
+#define RBD_RNEA_KERNEL_BATCH 1
+#define RBD_RNEA_KERNEL_GROUPS 2
 #define RBD_MINV_PHASE_A_AUTO 0
 #define RBD_MINV_PHASE_A_LANE 1
 #define RBD_MINV_PHASE_A_IA8 2

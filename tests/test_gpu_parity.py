@@ -80,9 +80,22 @@ def test_library_loaded_is_the_hip_one(name):
 
 
 @pytest.mark.parametrize("name", all_golden_names())
-def test_rnea_vs_golden(name, prec):
+@pytest.mark.parametrize("rnea_kernel", ["batch", "groups"])
+def test_rnea_vs_golden(name, prec, rnea_kernel):
+    """Both rnea kernels: one lane per configuration, and one wave per independent root subtree (what AUTO
+    picks for small batches of robots with several roots; a robot without such groups ignores the option)."""
+    from rbdreference_amd._lib import (RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO, RBD_RNEA_KERNEL_BATCH,
+                                       RBD_RNEA_KERNEL_GROUPS)
     dt, tol = prec
     g = load_golden(name); rbd = rbd_for(name)
+    rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_BATCH if rnea_kernel == "batch" else RBD_RNEA_KERNEL_GROUPS)
+    try:
+        _rnea_vs_golden(rbd, g, dt, tol)
+    finally:
+        rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO)
+
+
+def _rnea_vs_golden(rbd, g, dt, tol):
     q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
     c, v, a, f = rbd.rnea(q, qd, qdd)
     check("c", c, g["c"], tol); check("v", v, g["fpass_v"], tol); check("a", a, g["fpass_a"], tol)
