@@ -28,41 +28,6 @@
 
 namespace rbdk {
 
-// ---- compile-time body constants ---------------------------------------------------------------
-constexpr double cabs_(double x) { return x < 0 ? -x : x; }
-constexpr double Et_(int j, int r, int c) { return XT[j][r * 6 + c]; }              // E_tree
-constexpr double rx_(int j, int r, int c) {                                         // (r_tree)^x = -E^T B
-  double s = 0;
-  for (int m = 0; m < 3; ++m) s -= XT[j][m * 6 + r] * XT[j][(3 + m) * 6 + c];
-  return s;
-}
-constexpr double rt_(int j, int k) { return k == 0 ? rx_(j, 2, 1) : k == 1 ? rx_(j, 0, 2) : rx_(j, 1, 0); }
-constexpr double mass_(int j) { return IM[j][3 * 6 + 3]; }
-constexpr double hb_(int j, int k) {   // h = m c from the top-right block H = h^x
-  return k == 0 ? IM[j][2 * 6 + 3 + 1] : k == 1 ? IM[j][0 * 6 + 3 + 2] : IM[j][1 * 6 + 3 + 0];
-}
-constexpr double com_(int j, int k) { return hb_(j, k) / mass_(j); }
-constexpr double Ic_(int j, int r, int c) {   // inertia about the centre of mass: Ibar + m (c c^T - |c|^2 1)
-  const double cc = com_(j, 0) * com_(j, 0) + com_(j, 1) * com_(j, 1) + com_(j, 2) * com_(j, 2);
-  return IM[j][r * 6 + c] + mass_(j) * (com_(j, r) * com_(j, c) - (r == c ? cc : 0.0));
-}
-constexpr bool rigid_inertia_(int j) {
-  const double m = mass_(j);
-  if (!(m > 0)) return false;
-  const double tol = 1e-12 * (m > 1 ? m : 1);
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) {
-      if (cabs_(IM[j][(3 + r) * 6 + 3 + c] - (r == c ? m : 0.0)) > tol) return false;          // m 1
-      if (cabs_(IM[j][r * 6 + 3 + c] + IM[j][c * 6 + 3 + r]) > tol) return false;              // H skew
-      if (cabs_(IM[j][(3 + r) * 6 + c] - IM[j][c * 6 + 3 + r]) > tol) return false;            // lower-left = H^T
-    }
-  return true;
-}
-constexpr int n_children_(int i) {
-  int k = 0;
-  for (int j = 0; j < N; ++j) k += (PARENT[j] == i) ? 1 : 0;
-  return k;
-}
 constexpr bool grad_idsva_ok_() {
   if (!GRAD_PER_ROOT) return false;
   for (int j = 0; j < N; ++j) {

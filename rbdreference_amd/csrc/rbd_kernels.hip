@@ -996,9 +996,14 @@ __global__ __launch_bounds__(64) void minv_ia_kernel(const T* __restrict__ q, lo
 // group only ever meet the bodies of that group.  Every group gets its own blocks (lanes per
 // configuration = the group's column count rounded up to 8 / 16 / 32 / 64), which cuts the serial
 // body loop of a wave from n to the group's size (Atlas: 30 -> 18 / 6 / 6).
-constexpr int minv_lc(int rows) { return rows <= 8 ? 8 : rows <= 16 ? 16 : rows <= 32 ? 32 : 64; }
+// lanes per configuration = the group's column count exactly (Atlas' torso group: 3 x 18 of 64 lanes
+// instead of 2 x 32; the lanes beyond CPB * rows repeat the last column and store nothing)
+constexpr int minv_lc(int rows) { return rows <= 64 ? rows : 64; }
 constexpr int minv_cpb(int rt) { return 64 / minv_lc(grp_rows(rt)); }              // configurations per wave
-constexpr int minv_ts(int rt) { return (grp_rows(rt) * N) | 1; }                   // LDS tile stride (odd)
+// LDS tile stride between the configurations of a block: a multiple of 4 scalars (+4) when the group's rows
+// can leave as 16-byte pieces, otherwise odd
+constexpr bool minv_vec_flush(int rt) { return (grp_rows(rt) * N) % 4 == 0 && (N * N) % 4 == 0 && (grp_row0(rt) * N) % 4 == 0; }
+constexpr int minv_ts(int rt) { return minv_vec_flush(rt) ? grp_rows(rt) * N + 4 : (grp_rows(rt) * N) | 1; }
 template <class T>
 constexpr size_t minv_cols_lds_bytes() {
   size_t m = 0;
@@ -1030,9 +1035,11 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
   T* wsl = reinterpret_cast<T*>(smem_raw);                 // [CPB][rows][MINV_WS] per-body records
   T* tile = wsl + CPB * rows * MINV_WS;                    // [CPB][TS] image of the group's rows (full width n)
   const int lane = threadIdx.x;
-  const int jl = lane % LC;              // this lane's column within the group
+  const int slot0 = lane / LC;
+  const bool spare = slot0 >= CPB;       // lanes beyond CPB * rows
+  const int slot = spare ? CPB - 1 : slot0;
+  const int jl = spare ? LC - 1 : lane - slot0 * LC;   // this lane's column within the group
   const int j = row0 + jl;               // ... and in the matrix
-  const int slot = lane / LC;
   const long long cfg0 = blk * CPB;
   const long long rem = B - cfg0;
   const int nvalid = rem < CPB ? (int)rem : CPB;
@@ -1118,7 +1125,7 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
   });
   // ---- symmetrise (:799-804) through LDS, then stream the group's rows out -----------------------
   T* myt = tile + slot * TS - row0 * N;                    // myt[i * N + c], rows of this group
-  if (jl < rows) {
+  if (!spare) {
     sfor<row0, row0 + rows>([&](auto I) {
       constexpr int i = decltype(I)::value;
       if (i <= j) myt[i * N + j] = mcol[i];
@@ -1130,9 +1137,9 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
     // forward_dynamics epilogue (:1371-1374): qdd = Minv (u - c); lane j owns row j of the dense tile.
     // (u - c) is parked in the record area, which both sweeps have finished reading.
     T* tau = wsl + slot * rows - row0;                     // tau[k], k in the group
-    if (jl < rows && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
+    if (!spare && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
     __syncthreads();
-    if (jl < rows && slot < nvalid) {
+    if (!spare && slot < nvalid) {
       T o = T(0);
       sfor<row0, row0 + rows>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[j * N + k], tau[k], o); });
       qdd_out[(cfg0 + slot) * N + j] = o;
@@ -1141,12 +1148,25 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
   if (Minv != nullptr) {
     constexpr int RW = rows * N;
     T* gdst = Minv + cfg0 * (N * N) + row0 * N;
-    const int total = nvalid * RW;
+    if constexpr (minv_vec_flush(RT) && sizeof(T) == 4) {
+      // the group's rows of a configuration are RW contiguous scalars, 16-byte aligned at both ends
+      typedef T V __attribute__((ext_vector_type(4)));
+      constexpr int RV = RW / 4;
+      const int total = nvalid * RV;
+#pragma unroll 2
+      for (int g = lane; g < total; g += 64) {
+        const int cfg = g / RV;
+        const int r4 = g - cfg * RV;
+        reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = reinterpret_cast<const V*>(tile + cfg * TS)[r4];
+      }
+    } else {
+      const int total = nvalid * RW;
 #pragma unroll 4
-    for (int g = lane; g < total; g += 64) {
-      const int cfg = g / RW;
-      const int r2 = g - cfg * RW;
-      gdst[(long long)cfg * (N * N) + r2] = tile[cfg * TS + r2];
+      for (int g = lane; g < total; g += 64) {
+        const int cfg = g / RW;
+        const int r2 = g - cfg * RW;
+        gdst[(long long)cfg * (N * N) + r2] = tile[cfg * TS + r2];
+      }
     }
   }
 }
@@ -1604,16 +1624,16 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
     if (e != hipSuccess) return hip_fail(e, "rbd_minv launch");
     return 0;
   } else {
-  const size_t need = (size_t)B * N * MINV_WS * sizeof(T);
+  const size_t need = (size_t)B * MINV_WS_PER_CFG * sizeof(T);
   if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
-  const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B);
-  if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   hipStream_t s = (hipStream_t)stream;
   T* ws = reinterpret_cast<T*>(workspace);
+  const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
+  const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B);
+  if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
   // otherwise eight lanes per configuration (rbd_minv_ia8.h)
-  const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
   if (pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4)) {
     hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
   } else {
