@@ -176,3 +176,20 @@ def test_fp32_kernels_of_built_libraries_do_not_spill():
             if "<float" in name and scratch:
                 bad.append((os.path.basename(lib), name, spill, scratch))
     assert not bad, bad
+
+
+def test_robot_name_cannot_inject_code_into_the_generated_header():
+    """the name comes from the caller or from a URDF's <robot name=...>; the generated header is
+    compiled and dlopen'ed in-process, so only [A-Za-z0-9_] (at most 63 characters) may reach it or the file name."""
+    from rbdreference_amd.build import lib_path
+    from rbdreference_amd.packer import emit_header, safe_name
+    evil = 'x"; static int pwn = system("id"); //\\ \n#error boom \u00e9'
+    m = pack_robot(iiwa_like(), evil)
+    hdr = emit_header(m)
+    line = [l for l in hdr.splitlines() if l.startswith("#define RBD_MODEL_NAME")][0]
+    inside = line.split('"')[1]
+    assert line.count('"') == 2 and inside == safe_name(evil) and inside.replace("_", "").isalnum() and inside.isascii()
+    assert "system(" not in hdr and "#error" not in hdr and "\\" not in hdr
+    assert all(ch.isalnum() or ch in "_." for ch in os.path.basename(lib_path(m)))
+    assert len(safe_name("a" * 200)) == 63 and safe_name("") == "robot"
+    assert pack_robot(iiwa_like(), evil).hash == pack_robot(iiwa_like()).hash      # the name is not part of the model

@@ -15,9 +15,12 @@ if "atlas" in which:
 if "quad" in which:
     r = RBDReference(quadruped_like(), build=False); q, qd, qdd = inputs(65536, 12, 4, torch.float64)
     for _ in range(REPS): r.rnea_grad(q, qd, qdd, return_c=True); r.minv(q)
+if "iiwa4k" in which:     # BASELINE configs[1] alone: rnea + rnea_grad in one call at B = 4096
+    r = RBDReference(iiwa_like(), build=False); q, qd, qdd = inputs(4096, 7, 1, torch.float32)
+    for _ in range(REPS): r.rnea_and_grad(q, qd, qdd)
 if "iiwa" in which:
     r = RBDReference(iiwa_like(), build=False); q, qd, qdd = inputs(4096, 7, 1, torch.float32)
-    for _ in range(REPS): r.rnea(q, qd, qdd); r.rnea_grad(q, qd, qdd, return_c=True); r.minv(q)
+    for _ in range(REPS): r.rnea(q, qd, qdd); r.rnea_grad(q, qd, qdd, return_c=True); r.minv(q); r.rnea_and_grad(q, qd, qdd)
     q, qd, qdd = inputs(1 << 20, 7, 3, torch.float32)
     for _ in range(REPS): r.rnea(q, qd, qdd); r.minv(q); r.aba(q, qd, qdd)
     for _ in range(max(2, REPS // 4)): r.forward_dynamics_grad(q, qd, qdd)
