@@ -21,8 +21,11 @@
  * owns indices 0..5 of q, qd, qdd, c (q[0:6] = px, py, pz, rx, ry, rz of the world -> base transform,
  * qd[0:6] = the base twist in base coordinates), body i >= 1 owns index i + 5; "n" in the shapes
  * below then reads nv = n + 5 for q, qd, qdd, c, u, Minv and stays the body count for v, a, f.  Such a
- * library serves rbd_rnea, rbd_minv and rbd_forward_dynamics; every other entry point returns
- * RBD_ERR_UNSUPPORTED (the reference's own crba / aba raise for floating bases).
+ * library serves rbd_rnea, rbd_rnea_grad and rbd_rnea_with_grad -- dc_du [B, nv, 2 nv]; the base's six position
+ * columns are derivatives along a base-frame twist, as in the reference, :1168-1175; robots with fewer
+ * than six bodies are refused: the reference raises IndexError for them, :1168 -- rbd_minv and
+ * rbd_forward_dynamics; every other entry point returns RBD_ERR_UNSUPPORTED (the reference's own
+ * crba / aba raise for floating bases).
  */
 #ifndef RBD_HIP_H
 #define RBD_HIP_H

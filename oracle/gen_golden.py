@@ -108,7 +108,9 @@ def fb_robots():
     """Floating-base fixtures: the reference's floating-base branches of rnea / minv /
     forward_dynamics on duck-typed robots -- a trunk with four legs, and a 6-body tree with dense frames."""
     return [("fb_quadruped_like", floating_quadruped_like(), 301),
-            ("fb_random_tree_n6", FloatingBaseRobot(random_tree([-1, 0, 1, 0, 3, 3], seed=5, name="t6"), "fb_random_tree_n6"), 302)]
+            ("fb_random_tree_n6", FloatingBaseRobot(random_tree([-1, 0, 1, 0, 3, 3], seed=5, name="t6"), "fb_random_tree_n6"), 302),
+            # fewer than six bodies: the reference's rnea_grad raises (:1168), recorded in reference_raises
+            ("fb_random_tree_n4", FloatingBaseRobot(random_tree([-1, 0, 1, 1], seed=9, name="t4"), "fb_random_tree_n4"), 303)]
 
 
 def run_reference_fb(robot, q, qd, qdd):
@@ -128,6 +130,10 @@ def run_reference_fb(robot, q, qd, qdd):
         out["mb_Minv"].append(Mb.copy()); out["mb_F"].append(F.copy()); out["mb_U"].append(U.copy()); out["mb_Dinv"].append(D.copy())
         out["Minv_dense"].append(ref.minv(qs, True).copy()); out["Minv_upper"].append(ref.minv(qs, False).copy())
         out["fd_qdd"].append(np.asarray(ref.forward_dynamics(qs, qds, qdds)).copy())
+        if robot.get_num_bodies() >= 6:      # below, the reference's floating-base rnea_grad raises IndexError (:1168)
+            out.setdefault("dc_du", []).append(ref.rnea_grad(qs, qds, qdds).copy())
+            out.setdefault("dc_du_noqdd", []).append(ref.rnea_grad(qs, qds).copy())
+            out.setdefault("dc_du_damped", []).append(ref.rnea_grad(qs, qds, qdds, USE_VELOCITY_DAMPING=True).copy())
     data = {k: np.stack(vv) for k, vv in out.items()}
     raises = []
     for nm, fn in (("rnea_grad", lambda: ref.rnea_grad(q[0], qd[0], qdd[0])), ("crba", lambda: ref.crba(q[0])),

@@ -22,7 +22,7 @@ import numpy as np
 from . import rbd_oracle as fx
 
 __all__ = ["FbModel", "model_from_robot", "Xmats", "rnea_fpass", "rnea_bpass", "rnea", "minv_bpass",
-           "minv_fpass", "minv", "forward_dynamics", "joint_space_inertia"]
+           "minv_fpass", "minv", "forward_dynamics", "joint_space_inertia", "rnea_grad"]
 
 
 @dataclass
@@ -35,6 +35,7 @@ class FbModel:
     I: np.ndarray           # [nb, 6, 6]
     joints: fx.OracleModel  # X(q) fits of bodies 1.. (index 0 is a dummy identity joint)
     base_X: object          # callable q6 -> 6x6 (get_Xmat_Func_by_id(0))
+    damping: np.ndarray = None   # [nb] get_damping_by_id
 
 
 def model_from_robot(robot) -> FbModel:
@@ -70,7 +71,8 @@ def model_from_robot(robot) -> FbModel:
     for i in range(1, nb):
         assert int(robot.get_joint_index_q(i)) == i + 5 and int(robot.get_joint_index_v(i)) == i + 5
     jm = fx.model_from_robot(_View())
-    return FbModel(nb, nb + 5, jm.parent, jm.subtree, jm.S, jm.I, jm, robot.get_Xmat_Func_by_id(0))
+    damp = np.array([float(robot.get_damping_by_id(i)) for i in range(nb)])
+    return FbModel(nb, nb + 5, jm.parent, jm.subtree, jm.S, jm.I, jm, robot.get_Xmat_Func_by_id(0), damp)
 
 
 def Xmats(m: FbModel, q: np.ndarray) -> np.ndarray:
@@ -228,3 +230,76 @@ def joint_space_inertia(m: FbModel, q):
         e = np.zeros((B, m.n)); e[:, k] = 1.0
         H[:, :, k] = rnea(m, q, z, e, GRAVITY=0.0)[0] - c0
     return H[0] if unb else H
+
+
+def rnea_grad(m: FbModel, q, qd, qdd=None, GRAVITY=-9.81, USE_VELOCITY_DAMPING=False):
+    """RBDReference.rnea_grad (:1345-1368) with the floating-base branches of its four passes (:1141-1147,
+    :1165-1175, :1212-1243, :1267-1294, :1309-1341), restated column by column.  The base's six "position"
+    columns are derivatives along a base-frame twist (the reference perturbs X_0 with crm(.) S, S = eye(6)), not
+    along the six coordinates of q[0:6].  Only defined for NB >= 6: the reference's dq forward pass indexes
+    bodies 0..5 for the base (:1168) and raises IndexError on smaller robots; on larger ones those updates
+    add zeros, and its result agrees with central differences.  Literal quirks kept: velocity damping is
+    added at matrix index `ind` (the BODY id, :1341) and, for the base, to a whole 5 x 5 block (:1339)."""
+    assert m.nb >= 6, "the reference's floating-base rnea_grad raises IndexError for NB < 6 (:1168)"
+    q, unb = _batch(q, m.n); qd, _ = _batch(qd, m.n)
+    qdd_b = None if qdd is None else _batch(qdd, m.n)[0]
+    B = q.shape[0]; n = m.n; nb = m.nb
+    c, v, a, f = rnea(m, q, qd, qdd_b, GRAVITY)
+    X = Xmats(m, q)
+    g = np.zeros(6); g[5] = -GRAVITY
+    dc = np.zeros((B, n, 2 * n))
+    crm = fx._crm
+    for col in range(n):
+        for isqd in (False, True):
+            dv = np.zeros((B, nb, 6)); da = np.zeros((B, nb, 6)); df = np.zeros((B, nb, 6))
+            for i in range(nb):
+                p = m.parent[i]
+                if i == 0:
+                    if col < 6:
+                        e = np.zeros(6); e[col] = 1.0
+                        if isqd:
+                            dv[:, 0] = e                                                        # :1231  dv[:, inds_v, 0] += S
+                        else:
+                            da[:, 0] = np.einsum("bij,j->bi", crm(X[:, 0] @ g), e)            # :1175  crm(X a_grav) S
+                    if isqd:
+                        da[:, 0] += np.einsum("bij,bj->bi", crm(dv[:, 0]), qd[:, 0:6])        # :1236-1238  sum_ii qd_ii crm(dv) S[ii]
+                        if col < 6:
+                            da[:, 0, :] += crm(v[:, :, 0])[:, :, col]                          # :1243  crm(v) S
+                else:
+                    idx = i + 5
+                    Xi = X[:, i]
+                    dv[:, i] = np.einsum("bij,bj->bi", Xi, dv[:, p])                          # :1158 / :1230
+                    da[:, i] = np.einsum("bij,bj->bi", Xi, da[:, p])                          # :1163 / :1234
+                    if col == idx:
+                        if isqd:
+                            dv[:, i] += m.S[i]                                                  # :1231
+                        else:
+                            dv[:, i] += np.einsum("bij,j->bi", crm(np.einsum("bij,bj->bi", Xi, v[:, :, p])), m.S[i])   # :1159
+                    da[:, i] += qd[:, idx][:, None] * np.einsum("bij,j->bi", crm(dv[:, i]), m.S[i])   # :1170 / :1240
+                    if col == idx:
+                        if isqd:
+                            da[:, i] += np.einsum("bij,j->bi", crm(v[:, :, i]), m.S[i])       # :1243
+                        else:
+                            da[:, i] += np.einsum("bij,j->bi", crm(np.einsum("bij,bj->bi", Xi, a[:, :, p])), m.S[i])   # :1173
+                Iv = np.einsum("ij,bj->bi", m.I[i], v[:, :, i])
+                df[:, i] = (np.einsum("ij,bj->bi", m.I[i], da[:, i]) + fx._fxv(dv[:, i], Iv)
+                            + fx._fxv(v[:, :, i], np.einsum("ij,bj->bi", m.I[i], dv[:, i])))   # :1179-1185 / :1247-1252
+            out = n + col if isqd else col
+            for i in range(nb - 1, -1, -1):
+                p = m.parent[i]
+                if i == 0:
+                    dc[:, 0:6, out] = df[:, 0]                                                  # :1282 / :1325 with S = eye(6)
+                else:
+                    idx = i + 5
+                    dc[:, idx, out] = np.einsum("j,bj->b", m.S[i], df[:, i])                  # :1284 / :1325
+                    add = df[:, i].copy()
+                    if (not isqd) and col == idx:
+                        add += -np.einsum("bij,j->bi", crm(f[:, :, i]), m.S[i])               # :1292-1294  fxS(S, f) = -crm(f) S
+                    df[:, p] += np.einsum("bji,bj->bi", X[:, i], add)                         # :1291 / :1331
+    if USE_VELOCITY_DAMPING:                                                                     # :1336-1341, literally
+        for ind in range(nb):
+            if m.parent[ind] == -1:
+                dc[:, ind:ind + 5, n + ind:n + ind + 5] += m.damping[ind]
+            else:
+                dc[:, ind, n + ind] += m.damping[ind]
+    return dc[0] if unb else dc

@@ -289,12 +289,14 @@ class RBDReference:
                   return_c: bool = False):
         """RBDReference.rnea_grad (``RBDReference.py:1345-1368``) -> ``dc_du = [dc_dq | dc_dqd]``,
         ``(n, 2n)`` per configuration.  ``return_c=True`` also returns the bias force ``c`` the
-        reference computes internally (``:1353``) -> ``(c, dc_du)``."""
+        reference computes internally (``:1353``) -> ``(c, dc_du)``.  Floating base: ``n = NB + 5`` and the
+        base's six position columns are derivatives along a base-frame twist, as in the reference; robots
+        with fewer than six bodies are refused (the reference raises IndexError for them, ``:1168``)."""
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         with torch.cuda.device(dev):
-            dc = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
-            c = torch.empty((B, self.n), device=dev, dtype=dt) if return_c else None
+            dc = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
+            c = torch.empty((B, self.nv), device=dev, dtype=dt) if return_c else None
             st = torch.cuda.current_stream(dev).cuda_stream
             self._lib.check(self._fn("rbd_rnea_grad", dt)(
                 self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY),
@@ -310,11 +312,11 @@ class RBDReference:
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         with torch.cuda.device(dev):
-            c = torch.empty((B, self.n), device=dev, dtype=dt)
+            c = torch.empty((B, self.nv), device=dev, dtype=dt)
             v = torch.empty((B, 6, self.n), device=dev, dtype=dt)
             a = torch.empty_like(v)
             f = torch.empty_like(v)
-            dc = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
+            dc = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
             self._lib.check(self._fn("rbd_rnea_with_grad", dt)(
                 self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B,

@@ -14,8 +14,11 @@
 //                      body j - 5): its F vector climbs the root path, the base block gives rows 0..5,
 //                      the forward sweep gives rows 6.. -- the reference's (n, 6, n) F tensor never exists.
 //   forward_dynamics (:1371-1374)  Minv (u - c) by composition (rnea with qdd = None, minv, one product).
-// The reference's rnea_grad runs for floating bases only when NB >= 6 (:1168 indexes bodies 0..5), its
-// crba (:1063) and aba (:900) raise: not part of this file.
+//   rnea_grad (:1345-1368)  the four passes with their floating-base branches; the base's six position
+//                      columns are derivatives along a base-frame twist (crm(.) S with S = eye(6)).  The
+//                      reference runs only when NB >= 6 (:1168 indexes bodies 0..5 and raises IndexError
+//                      otherwise): the entry point reports smaller robots as unsupported.
+// The reference's crba (:1063) and aba (:900) raise for floating bases: not part of this file.
 //
 // These are correctness-first kernels (a "next" row): one configuration per lane, scattered stores.
 #pragma once
@@ -260,6 +263,188 @@ __global__ __launch_bounds__(256) void fb_apply_kernel(const T* __restrict__ Min
   T o = T(0);
   for (int k = 0; k < NV; ++k) o = fma_(M[k], u[b * NV + k] - c[b * NV + k], o);
   qdd[g] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rnea_grad: (q, qd, qdd) [B, NV] -> dc_du [B, NV, 2 NV] (and c [B, NV]), one configuration per lane.
+// Column by column, as the reference's dense (6, n, NB) updates do (:1139-1185, :1210-1252, :1264-1294,
+// :1306-1341): for every derivative column the lane sweeps the bodies forward (dv, da, df) and backward
+// (dc[:, col]).  v stays in registers; a (read once per column, by the own-column term), the accumulated f
+// and the column's df of every body live in LDS ([6 N][64] each, one bank per lane).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+constexpr bool grad_fb_ok() { return N >= 6 && (size_t)3 * 6 * N * 64 * sizeof(T) <= 160 * 1024; }
+
+template <class T>
+RBD_DEV void crm_mul(const T (&x)[6], const T (&y)[6], T (&o)[6]) {   // o = crm(x) y   (:131-140)
+  o[0] = x[1] * y[2] - x[2] * y[1];
+  o[1] = x[2] * y[0] - x[0] * y[2];
+  o[2] = x[0] * y[1] - x[1] * y[0];
+  o[3] = x[1] * y[5] - x[2] * y[4] + x[4] * y[2] - x[5] * y[1];
+  o[4] = x[2] * y[3] - x[0] * y[5] + x[5] * y[0] - x[3] * y[2];
+  o[5] = x[0] * y[4] - x[1] * y[3] + x[3] * y[1] - x[4] * y[0];
+}
+
+template <class T, bool HAS_QDD>
+__global__ __launch_bounds__(64, 1) void rnea_grad_fb_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+                                                             const T* __restrict__ qdd, T grav, int use_damping,
+                                                             long long B, T* __restrict__ c_out, T* __restrict__ dcdu) {
+  static_assert(grad_fb_ok<T>(), "instantiated by the launch code only when grad_fb_ok");
+  __shared__ T facc[6 * N][64];
+  __shared__ T dfl[6 * N][64];
+  __shared__ T acl[6 * N][64];
+  const int lane = threadIdx.x;
+  const long long b = (long long)blockIdx.x * 64 + lane;
+  if (b >= B) return;                                   // no barriers below: a lane only ever touches its own LDS column
+  const T* qb = q + b * NV; const T* qdb = qd + b * NV; const T* qddb = HAS_QDD ? qdd + b * NV : nullptr;
+  JTrig<T> tr[N];
+  T qdv[N];
+  T v[N][6];
+  T ag0[6];                                             // X_0 a_grav
+  {
+    // rnea (:559-621): a and the local f go to LDS as they are produced, the backward pass accumulates f there
+    auto put = [&](T (&dst)[6 * N][64], int j, const T (&x)[6]) {
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dst[6 * j + r][lane] = x[r]; });
+    };
+    auto get = [&](T (&src)[6 * N][64], int j, T (&x)[6]) {
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; x[r] = src[6 * j + r][lane]; });
+    };
+    T E[3][3];
+    fb_base_E(qb[3], qb[4], qb[5], E);
+    ag0[0] = ag0[1] = ag0[2] = T(0);
+    ag0[3] = -(grav * E[0][2]); ag0[4] = -(grav * E[1][2]); ag0[5] = -(grav * E[2][2]);
+    {
+      T a0[6], f0[6], Iv[6], Ia[6];
+      sfor<0, 6>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        v[0][r] = qdb[r];
+        a0[r] = (HAS_QDD ? qddb[r] : T(0)) + ag0[r];
+      });
+      cmatvec<MatI, 0>(v[0], Iv);
+      cmatvec<MatI, 0>(a0, Ia);
+      sfor<0, 6>([&](auto R) { f0[decltype(R)::value] = Ia[decltype(R)::value]; });
+      fxv<true>(v[0], Iv, f0);
+      put(acl, 0, a0);
+      put(facc, 0, f0);
+    }
+    sfor<1, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      tr[j] = make_trig<j>(qb[j + 5]);
+      qdv[j] = qdb[j + 5];
+      T qddj = T(0);
+      if constexpr (HAS_QDD) qddj = qddb[j + 5];
+      T xv[6], xa[6], ap[6], aj[6], fj[6];
+      get(acl, p, ap);
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddj, grav, v[p], ap, xv, xa, v[j], aj, fj);
+      put(acl, j, aj);
+      put(facc, j, fj);
+    });
+    sfor_down<1, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      T fj[6], t[6];
+      get(facc, j, fj);
+      if (c_out != nullptr) c_out[b * NV + j + 5] = S_dot<j>(fj);
+      xform_T<j>(tr[j], fj, t);
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; facc[6 * p + r][lane] += t[r]; });
+    });
+    if (c_out != nullptr) sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; c_out[b * NV + r] = facc[r][lane]; });
+  }
+  T* dcb = dcdu + b * (2 * NV * NV);
+#pragma clang loop unroll(disable)
+  for (int out = 0; out < 2 * NV; ++out) {
+    const bool isqd = out >= NV;
+    const int col = isqd ? out - NV : out;
+    // Column-invariant products (X v_p, X a_p, I v, crm(.) S of every body) would be hoisted out of this
+    // loop and kept live across it: ~30 N values, i.e. scratch.  Opaque copies keep them inside the iteration.
+    sfor<1, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j].s = launder(tr[j].s); tr[j].c = launder(tr[j].c); });
+    sfor<0, N>([&](auto J) {
+      sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; v[j][r] = launder(v[j][r]); });
+    });
+    // ---- forward sweep of the column ---------------------------------------------------------------
+    T dv[N][6], da[N][6];
+    {
+      // the base: dq: dv = 0, da = crm(X_0 a_grav) e_col (:1175); dqd: dv = e_col (:1231),
+      // da = crm(dv) v_0 (:1236-1238, sum_ii qd_ii crm(dv) e_ii) + crm(v_0) e_col (:1243)
+      T e[6];
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; e[r] = col == r ? T(1) : T(0); });
+      T t0[6], t1[6], t2[6];
+      crm_mul(ag0, e, t0);
+      crm_mul(e, v[0], t1);
+      crm_mul(v[0], e, t2);
+      sfor<0, 6>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        dv[0][r] = sel(isqd, e[r], T(0));
+        da[0][r] = sel(isqd, t1[r] + t2[r], t0[r]);
+      });
+      T Iv[6], Idv[6], d[6];
+      cmatvec<MatI, 0>(v[0], Iv);
+      cmatvec<MatI, 0>(dv[0], Idv);
+      cmatvec<MatI, 0>(da[0], d);
+      fxv<true>(dv[0], Iv, d);
+      fxv<true>(v[0], Idv, d);
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dfl[r][lane] = d[r]; });
+    }
+    sfor<1, N>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int p = PARENT[i];
+      const bool own = col == i + 5;
+      xform<i>(tr[i], dv[p], dv[i]);          // (:1158 / :1230)
+      xform<i>(tr[i], da[p], da[i]);          // (:1163 / :1234)
+      T xv[6], xa[6], ap[6], sdq[6], sS[6], e1[6], e2[6];
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; ap[r] = acl[6 * p + r][lane]; });
+      xform<i>(tr[i], v[p], xv);
+      xform<i>(tr[i], ap, xa);
+      mxS<i>(xv, T(1), sdq);                  // crm(X v_p) S   (:1159)
+      sfor<0, 6>([&](auto R) { sS[decltype(R)::value] = T(0); });
+      add_S<i>(T(1), sS);                     // S              (:1231)
+      mxS<i>(xa, T(1), e1);                   // crm(X a_p) S   (:1173)
+      mxS<i>(v[i], T(1), e2);                 // crm(v_i) S     (:1243)
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dv[i][r] += sel(own, sel(isqd, sS[r], sdq[r]), T(0)); });
+      add_mxS<i>(dv[i], qdv[i], da[i]);       // (:1170 / :1240)
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; da[i][r] += sel(own, sel(isqd, e2[r], e1[r]), T(0)); });
+      T Iv[6], Idv[6], d[6];
+      cmatvec<MatI, i>(v[i], Iv);
+      cmatvec<MatI, i>(dv[i], Idv);
+      cmatvec<MatI, i>(da[i], d);
+      fxv<true>(dv[i], Iv, d);                // (:1179-1185 / :1247-1252)
+      fxv<true>(v[i], Idv, d);
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dfl[(6 * i + r)][lane] = d[r]; });
+    });
+    // ---- backward sweep (:1264-1294 / :1306-1341) -----------------------------------------------------
+    sfor_down<1, N>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int p = PARENT[i];
+      T d[6], fi[6], w[6], x[6], y[6];
+      sfor<0, 6>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        d[r] = dfl[(6 * i + r)][lane];
+        fi[r] = facc[(6 * i + r)][lane];
+      });
+      T o = S_dot<i>(d);                                                  // (:1284 / :1325)
+      dcb[(i + 5) * (2 * NV) + out] = o;
+      mxS<i>(fi, T(-1), w);                                               // fxS(S, f) = -crm(f) S  (:1292-1294)
+      const bool ex = (col == i + 5) && !isqd;
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; x[r] = d[r] + sel(ex, w[r], T(0)); });
+      xform_T<i>(tr[i], x, y);                                            // (:1291 / :1331)
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dfl[(6 * p + r)][lane] += y[r]; });
+    });
+    sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dcb[r * (2 * NV) + out] = dfl[r][lane]; });   // S = eye(6) (:1282)
+  }
+  if (use_damping) {
+    // (:1336-1341) literally: the base adds its damping to a 5 x 5 block, body ind >= 1 to entry (ind, n + ind)
+    sfor<0, 5>([&](auto R) {
+      sfor<0, 5>([&](auto C) {
+        constexpr int r = decltype(R)::value, c = decltype(C)::value;
+        if constexpr (DAMPING[0] != 0.0) dcb[r * (2 * NV) + NV + c] += T(DAMPING[0]);
+      });
+    });
+    sfor<1, N>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (DAMPING[i] != 0.0) dcb[i * (2 * NV) + NV + i] += T(DAMPING[i]);
+    });
+  }
 }
 
 }  // namespace rbdk

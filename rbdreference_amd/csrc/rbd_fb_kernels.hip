@@ -2,8 +2,8 @@
 // comes from rbd_kernels.hip): rbd_fb.h's kernels behind the same C-ABI (include/rbd_hip.h).
 //
 // A floating-base library exports every symbol of the header; the entry points the reference itself
-// cannot serve for a floating base (its rnea_grad needs NB >= 6 and is not restated yet, its crba and aba
-// raise: RBDReference.py:1168, :1063, :900) and the per-pass / forward_dynamics_grad entry points return
+// cannot serve for a floating base (its crba and aba raise, its rnea_grad raises IndexError for NB < 6:
+// RBDReference.py:1063, :900, :1168) and the per-pass / forward_dynamics_grad entry points return
 // RBD_ERR_UNSUPPORTED with a message.  Shapes: q, qd, qdd, c, u [B, NV]; v, a, f [B, 6, N]; Minv [B, NV, NV].
 // Units: -DRBD_TU_FB_F32 / -DRBD_TU_FB_F64 (rbdreference_amd/build.py).
 #include "rbd_fb.h"
@@ -23,7 +23,8 @@ int hip_fail(hipError_t e, const char* where) {
 }
 int unsupported(const char* who) {
   std::snprintf(rbd_err_buf(), RBD_ERR_LEN,
-                "%s: not available for floating-base robots (supported: rbd_rnea, rbd_minv, rbd_forward_dynamics)", who);
+                "%s: not available for floating-base robots (supported: rbd_rnea, rbd_rnea_grad, rbd_rnea_with_grad, "
+                "rbd_minv, rbd_forward_dynamics)", who);
   return RBD_ERR_UNSUPPORTED;
 }
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -42,6 +43,34 @@ int rnea_fb_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, 
   else hipLaunchKernelGGL((rnea_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_rnea (floating base) launch");
+}
+template <class T>
+int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* v,
+                   T* a, T* f, T* dc_du, void* stream) {
+  using namespace rbdk;
+  if constexpr (!grad_fb_ok<T>()) {
+    std::snprintf(rbd_err_buf(), RBD_ERR_LEN,
+                  "%s: floating-base rnea_grad needs 6 <= NB (the reference raises IndexError below, RBDReference.py:1168) "
+                  "and 12 NB lanes-columns of LDS; this robot has NB = %d", who, N);
+    return RBD_ERR_UNSUPPORTED;
+  } else {
+    if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
+    if (B == 0) return 0;
+    if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
+    const bool vaf = v || a || f;
+    if (vaf && !(v && a && f && c)) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: c, v, a, f must be all non-null");
+    const int64_t blocks = (B + 63) / 64;
+    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+    if (vaf) {   // RBDReference.rnea's outputs: the rnea kernel's own launch
+      int rc = rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);
+      if (rc != 0) return rc;
+    }
+    T* cg = vaf ? nullptr : c;
+    if (qdd) hipLaunchKernelGGL((rnea_grad_fb_kernel<T, true>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+    else hipLaunchKernelGGL((rnea_grad_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "rbd_rnea_grad (floating base) launch");
+  }
 }
 template <class T>
 int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
@@ -85,7 +114,7 @@ __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f32(int64_t B, ch
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len);
 
 #define RBD_FB_DEFS(SFX, T)                                                                                                 \
-  int rbd_grad_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "(none: floating base)"); return 0; } \
+  int rbd_grad_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "rnea_grad_fb_kernel"); return 0; } \
   int rbd_minv_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "minv_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
   int rbd_rnea_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {   \
     return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \
@@ -99,8 +128,13 @@ __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, ch
   }                                                                                                                         \
   int rbd_rnea_fpass_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_fpass"); } \
   int rbd_rnea_bpass_##SFX(const T*, T*, int64_t, T*, void*) { return unsupported("rbd_rnea_bpass"); }                      \
-  int rbd_rnea_grad_##SFX(const T*, const T*, const T*, T, int, int64_t, T*, T*, void*) { return unsupported("rbd_rnea_grad"); } \
-  int rbd_rnea_with_grad_##SFX(const T*, const T*, const T*, T, int, int64_t, T*, T*, T*, T*, T*, void*) { return unsupported("rbd_rnea_with_grad"); } \
+  int rbd_rnea_grad_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* dc_du, void* stream) { \
+    return grad_fb_launch<T>("rbd_rnea_grad", q, qd, qdd, gravity, use_damping, B, c, nullptr, nullptr, nullptr, dc_du, stream); \
+  }                                                                                                                         \
+  int rbd_rnea_with_grad_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* v, T* a, T* f, \
+                               T* dc_du, void* stream) {                                                                    \
+    return grad_fb_launch<T>("rbd_rnea_with_grad", q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);          \
+  }                                                                                                                         \
   int rbd_rnea_grad_fpass_dq_##SFX(const T*, const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_grad_fpass_dq"); } \
   int rbd_rnea_grad_fpass_dqd_##SFX(const T*, const T*, const T*, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_grad_fpass_dqd"); } \
   int rbd_rnea_grad_bpass_dq_##SFX(const T*, const T*, T*, int64_t, T*, void*) { return unsupported("rbd_rnea_grad_bpass_dq"); } \

@@ -112,11 +112,6 @@ RBD_DEV void staged_store(T* lds, const T (&vals)[K], T* gdst, int lane, int nva
 // ---------------------------------------------------------------------------------------------
 // rnea:  (q, qd, qdd) -> c [B,n], v, a, f [B,6,n]   (f = ACCUMULATED force, :619, :628)
 // ---------------------------------------------------------------------------------------------
-// Opaque copy: the compiler cannot see that launder(x) == x, so values recomputed from laundered
-// inputs are NOT merged (CSE) with their first computation.  rnea_grad_kernel uses it to trade ~400
-// cheap instructions (the v/a recursion) for ~170 VGPRs that would otherwise stay live.
-RBD_DEV float launder(float x) { asm volatile("" : "+v"(x)); return x; }
-RBD_DEV double launder(double x) { asm volatile("" : "+v"(x)); return x; }
 
 // Ordering point: the six values pass through an empty volatile asm with a memory clobber, so code
 // that produces them stays above it and later memory reads stay below it.

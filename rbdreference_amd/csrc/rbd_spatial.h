@@ -35,6 +35,12 @@ RBD_DEV void sfor_down(F&& f) {
   }
 }
 
+// Opaque copy: the compiler cannot see that launder(x) == x, so values recomputed from laundered
+// inputs are NOT merged (CSE) with their first computation.  rnea_grad_kernel uses it to trade ~400
+// cheap instructions (the v/a recursion) for ~170 VGPRs that would otherwise stay live.
+RBD_DEV float launder(float x) { asm volatile("" : "+v"(x)); return x; }
+RBD_DEV double launder(double x) { asm volatile("" : "+v"(x)); return x; }
+
 // by-value select: `c ? x[i] : y[i]` on two lvalues is an lvalue conditional, which clang lowers to a
 // select of ADDRESSES and thereby forces the arrays into scratch memory.
 template <class T>

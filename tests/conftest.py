@@ -48,6 +48,8 @@ def make_robot(name):
         return floating_quadruped_like()
     if name == "fb_random_tree_n6":
         return FloatingBaseRobot(random_tree([-1, 0, 1, 0, 3, 3], seed=5, name="t6"), name)
+    if name == "fb_random_tree_n4":
+        return FloatingBaseRobot(random_tree([-1, 0, 1, 1], seed=9, name="t4"), name)
     if name == "random_tree_n9":
         return random_tree([-1, 0, 1, 1, 3, -1, 5, 5, 7], seed=7, name=name)
     if name == "random_chain_n7":

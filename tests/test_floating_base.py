@@ -1,5 +1,5 @@
-"""Floating base: the reference's floating-base branches of rnea / minv / forward_dynamics
-(RBDReference.py:585-593, :652-691, :761-779).
+"""Floating base: the reference's floating-base branches of rnea / rnea_grad / minv /
+forward_dynamics (RBDReference.py:585-593, :652-691, :761-779, :1141-1341).
 
 CPU part: the numpy restatement (oracle/rbd_oracle_fb.py) against golden vectors produced by the REAL reference
 on duck-typed floating-base robots (oracle/gen_golden.py), the packer's validation, and reference-free
@@ -32,6 +32,45 @@ def test_fb_oracle_vs_reference_golden(name):
     # unbatched call
     c1, v1, _, _ = fbo.rnea(m, g["q"][2], g["qd"][2], g["qdd"][2])
     assert c1.shape == (m.n,) and v1.shape == (6, m.nb) and rel_err(c1, g["c"][2]) <= TOL
+    if m.nb >= 6:
+        assert rel_err(fbo.rnea_grad(m, g["q"], g["qd"], g["qdd"]), g["dc_du"]) <= TOL
+        assert rel_err(fbo.rnea_grad(m, g["q"], g["qd"]), g["dc_du_noqdd"]) <= TOL
+        assert rel_err(fbo.rnea_grad(m, g["q"], g["qd"], g["qdd"], USE_VELOCITY_DAMPING=True), g["dc_du_damped"]) <= TOL
+        assert fbo.rnea_grad(m, g["q"][1], g["qd"][1], g["qdd"][1]).shape == (m.n, 2 * m.n)
+    else:
+        assert "dc_du" not in g
+        with pytest.raises(AssertionError):
+            fbo.rnea_grad(m, g["q"], g["qd"], g["qdd"])
+
+
+@pytest.mark.parametrize("name", [n for n in fb_golden_names() if n != "fb_random_tree_n4"])
+def test_fb_rnea_grad_is_the_derivative_of_rnea(name):
+    """Reference-free: central differences of rnea.  Joint columns (>= 6) of dc_dq and every column of dc_dqd
+    are coordinate derivatives; the base's six dc_dq columns are derivatives along a base-frame twist
+    (X_0 <- (1 - crm(e_k) h) X_0, :1168-1175), which moves gravity only: a_0 <- a_0 + h crm(X_0 a_grav) e_k."""
+    robot = make_robot(name); m = fbo.model_from_robot(robot)
+    rng = np.random.default_rng(5)
+    q = rng.uniform(-np.pi, np.pi, (2, m.n)); qd = rng.uniform(-1, 1, (2, m.n)); qdd = rng.uniform(-1, 1, (2, m.n))
+    dc = fbo.rnea_grad(m, q, qd, qdd)
+    h = 1e-6
+    for j in range(m.n):
+        e = np.zeros(m.n); e[j] = h
+        fd_qd = (fbo.rnea(m, q, qd + e, qdd)[0] - fbo.rnea(m, q, qd - e, qdd)[0]) / (2 * h)
+        assert np.abs(fd_qd - dc[:, :, m.n + j]).max() <= 1e-6 * max(1.0, np.abs(dc[:, :, m.n + j]).max()), ("dqd", j)
+        if j >= 6:
+            fd_q = (fbo.rnea(m, q + e, qd, qdd)[0] - fbo.rnea(m, q - e, qd, qdd)[0]) / (2 * h)
+            assert np.abs(fd_q - dc[:, :, j]).max() <= 1e-6 * max(1.0, np.abs(dc[:, :, j]).max()), ("dq", j)
+    # base twist columns: c is affine in a_0 through qdd[0:6], so the perturbed gravity term can ride on qdd
+    X0 = fbo.Xmats(m, q)[:, 0]
+    g0 = np.zeros(6); g0[5] = 9.81
+    from oracle import rbd_oracle as fx
+    for k in range(6):
+        ek = np.zeros(6); ek[k] = 1.0
+        da0 = np.einsum("bij,j->bi", fx._crm(X0 @ g0), ek)
+        qp = qdd.copy(); qp[:, 0:6] += h * da0
+        qm = qdd.copy(); qm[:, 0:6] -= h * da0
+        fd = (fbo.rnea(m, q, qd, qp)[0] - fbo.rnea(m, q, qd, qm)[0]) / (2 * h)
+        assert np.abs(fd - dc[:, :, k]).max() <= 1e-6 * max(1.0, np.abs(dc[:, :, k]).max()), ("base", k)
 
 
 @pytest.mark.parametrize("name", fb_golden_names())
@@ -51,11 +90,16 @@ def test_fb_invariants(name):
 
 def test_what_the_reference_cannot_do_is_on_record():
     """The fixtures record how the reference's other entry points behave on a floating base (generated with
-    the fixture, RBDReference.py line numbers): crba and aba raise; rnea_grad only runs because NB >= 6."""
+    the fixture, RBDReference.py line numbers): crba and aba raise; rnea_grad runs only when NB >= 6."""
     for name in fb_golden_names():
-        r = [str(x) for x in load_golden(name)["reference_raises"]]
+        g = load_golden(name)
+        r = [str(x) for x in g["reference_raises"]]
         assert any(x.startswith("crba: IndexError") and x.endswith(":1063") for x in r), r
         assert any(x.startswith("aba:") and x.endswith(":900") for x in r), r
+        if g["parent"].shape[0] >= 6:
+            assert "rnea_grad: ran" in r, r
+        else:
+            assert any(x.startswith("rnea_grad: IndexError") and x.endswith(":1168") for x in r), r
 
 
 def test_fb_packer_validation():
@@ -110,6 +154,15 @@ def test_fb_kernels_vs_golden(name, precision):
     chk("c", c, g["c"]); chk("v", v, g["fpass_v"]); chk("a", a, g["fpass_a"]); chk("f", f, g["f_acc"])
     chk("c_noqdd", rbd.rnea(q, qd)[0], g["c_noqdd"])
     chk("c only", rbd.rnea(q, qd, qdd, outputs="c")[0], g["c"])
+    if rbd.n >= 6:
+        tg = 1e-5 if dt == torch.float32 else 1e-11
+        chk("dc_du", rbd.rnea_grad(q, qd, qdd), g["dc_du"], tg)
+        chk("dc_du_noqdd", rbd.rnea_grad(q, qd), g["dc_du_noqdd"], tg)
+        chk("dc_du_damped", rbd.rnea_grad(q, qd, qdd, USE_VELOCITY_DAMPING=True), g["dc_du_damped"], tg)
+        c1, dc1 = rbd.rnea_grad(q, qd, qdd, return_c=True)
+        chk("c of rnea_grad", c1, g["c"]); chk("dc_du (with c)", dc1, g["dc_du"], tg)
+        c2, v2, a2, f2, dc2 = rbd.rnea_and_grad(q, qd, qdd)
+        assert torch.equal(dc2, dc1) and torch.equal(c2, c) and torch.equal(v2, v) and torch.equal(a2, a) and torch.equal(f2, f)
     Mi = rbd.minv(q)
     chk("Minv_dense", Mi, g["Minv_dense"])
     assert torch.equal(Mi, Mi.transpose(1, 2))
@@ -144,6 +197,9 @@ def test_fb_ragged_batches_vs_oracle(B):
     assert rel_err_rows(rbd.minv(tq).cpu().numpy(), fbo.minv(m, q)) <= 1e-11
     assert rel_err_rows(rbd.forward_dynamics(tq, tqd, tqdd).cpu().numpy(), fbo.forward_dynamics(m, q, qd, qdd)) <= 1e-9
     assert rel_err_rows(rbd.minv(tq.float()).double().cpu().numpy(), fbo.minv(m, q)) <= 1e-5
+    dcr = fbo.rnea_grad(m, q, qd, qdd)
+    assert rel_err_rows(rbd.rnea_grad(tq, tqd, tqdd).cpu().numpy(), dcr) <= 1e-11
+    assert rel_err_rows(rbd.rnea_grad(tq.float(), tqd.float(), tqdd.float()).double().cpu().numpy(), dcr) <= 1e-5
 
 
 @pytest.mark.gpu
@@ -152,7 +208,14 @@ def test_fb_unsupported_entry_points_say_so():
     from rbdreference_amd._lib import RBD_ERR_UNSUPPORTED, RbdError
     rbd = _rbd("fb_quadruped_like")
     q = torch.zeros((4, rbd.nv), device="cuda:0", dtype=torch.float32)
-    for call in (lambda: rbd.rnea_grad(q, q, q), lambda: rbd.aba(q, q, q), lambda: rbd.forward_dynamics_grad(q, q, q)):
+    for call in (lambda: rbd.crba(q), lambda: rbd.aba(q, q, q), lambda: rbd.forward_dynamics_grad(q, q, q)):
         with pytest.raises(RbdError) as ei:
             call()
         assert ei.value.code == RBD_ERR_UNSUPPORTED and "floating-base" in str(ei.value)
+    # fewer than six bodies: the reference's own rnea_grad raises IndexError (:1168, on record in the fixture)
+    small = _rbd("fb_random_tree_n4")
+    q = torch.zeros((4, small.nv), device="cuda:0", dtype=torch.float64)
+    for call in (lambda: small.rnea_grad(q, q, q), lambda: small.rnea_and_grad(q, q, q)):
+        with pytest.raises(RbdError) as ei:
+            call()
+        assert ei.value.code == RBD_ERR_UNSUPPORTED and "NB = 4" in str(ei.value)
