@@ -72,7 +72,9 @@ int rbd_model_info(rbd_model_info_t* out);
  *   RBD_OPT_MINV_PHASE_A   rbd_minv, two-phase robots: AUTO | LANE (one lane per configuration) |
  *                          IA8 (eight lanes per configuration)
  *   RBD_OPT_RNEA_KERNEL    rbd_rnea with v, a, f: AUTO | BATCH (one lane per configuration) | GROUPS (one
- *                          wave per independent root subtree: what AUTO picks for robots with several)
+ *                          wave per independent root subtree).  AUTO: robots whose root subtrees carry
+ *                          several big branches (Atlas' arms) get one wave per branch / stem / root
+ *                          subtree, other multi-root robots GROUPS, single chains BATCH
  * rbd_kernel_name writes the name of the kernel (the dominant one of a multi-launch entry point) that
  * `op` would launch for a batch of B rows of elem_size-byte scalars under the current options. */
 #define RBD_OPT_GRAD_KERNEL 0

@@ -112,9 +112,12 @@ __attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f32(int64_t B, ch
 __attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f32(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f64(int64_t B, char* buf, size_t len);
 
 #define RBD_FB_DEFS(SFX, T)                                                                                                 \
   int rbd_grad_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "rnea_grad_fb_kernel"); return 0; } \
+  int rbd_rnea_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "rnea_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
   int rbd_minv_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "minv_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
   int rbd_rnea_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {   \
     return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \

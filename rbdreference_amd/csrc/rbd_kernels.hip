@@ -137,6 +137,30 @@ constexpr size_t rnea_lds_bytes(bool vaf) {
   return (RNEA_PARK_VA && rnea_two_tiles<T>()) ? 2 * one : one;
 }
 
+// flush_tile for a block of NT threads (tid = dense rank of the participating thread)
+template <int K, int NT, class T>
+RBD_DEV void flush_tile_nt(const T* lds, T* gdst, int tid, int nvalid) {
+  constexpr int KP = odd_pad<K>();
+  constexpr int VE = 16 / sizeof(T);
+  if constexpr (KP == K && (64 * K) % VE == 0) {
+    if (nvalid == 64) {                  // unpadded tile: the LDS image is the HBM image, flat 16-byte copies
+      typedef T V __attribute__((ext_vector_type(VE)));
+      const V* src = reinterpret_cast<const V*>(lds);
+      V* dst = reinterpret_cast<V*>(gdst);
+#pragma unroll 4
+      for (int g = tid; g < 64 * K / VE; g += NT) dst[g] = src[g];
+      return;
+    }
+  }
+  const int total = nvalid * K;
+#pragma unroll 4
+  for (int g = tid; g < total; g += NT) {
+    const int cfg = g / K;
+    const int r = g - cfg * K;
+    gdst[g] = lds[cfg * KP + r];
+  }
+}
+
 #ifdef RBD_NEED_RNEA
 template <class T, bool HAS_QDD, bool WITH_VAF>
 __global__ __launch_bounds__(64) void rnea_kernel(const T* __restrict__ q, const T* __restrict__ qd,
@@ -428,29 +452,6 @@ constexpr bool rnea_groups_ok() {
   return GRAD_PER_ROOT && RG_WAVES > 1 && RG_WAVES <= 4 && 2ull * 64 * odd_pad<6 * N>() * sizeof(T) <= 150 * 1024;
 }
 
-template <int K, int NT, class T>
-RBD_DEV void flush_tile_nt(const T* lds, T* gdst, int tid, int nvalid) {
-  constexpr int KP = odd_pad<K>();
-  constexpr int VE = 16 / sizeof(T);
-  if constexpr (KP == K && (64 * K) % VE == 0) {
-    if (nvalid == 64) {                  // unpadded tile: the LDS image is the HBM image, flat 16-byte copies
-      typedef T V __attribute__((ext_vector_type(VE)));
-      const V* src = reinterpret_cast<const V*>(lds);
-      V* dst = reinterpret_cast<V*>(gdst);
-#pragma unroll 4
-      for (int g = tid; g < 64 * K / VE; g += NT) dst[g] = src[g];
-      return;
-    }
-  }
-  const int total = nvalid * K;
-#pragma unroll 4
-  for (int g = tid; g < total; g += NT) {
-    const int cfg = g / K;
-    const int r = g - cfg * K;
-    gdst[g] = lds[cfg * KP + r];
-  }
-}
-
 template <class T, bool HAS_QDD>
 __global__ __launch_bounds__(64 * RG_WAVES) void rnea_groups_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                                    const T* __restrict__ qdd, T grav, long long B,
@@ -537,6 +538,222 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rnea_groups_kernel(const T* __r
   __syncthreads();
   flush_tile_nt<K6, NT>(tileV, f_out + cfg0 * K6, tid, nvalid);
   if (c_out != nullptr) flush_tile_nt<N, NT>(tileA, c_out + cfg0 * N, tid, nvalid);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// rnea with one wave per SEGMENT: the group waves above still run a group's whole recursion as one serial
+// stream (Atlas torso: 18 forward + 18 backward body steps).  Big sibling subtrees of a group ("limbs": the two
+// arms under the third back joint) are independent of each other between the moment their parent's v, a
+// exist and the moment their root force goes back to it (:576-581, :618-619), so each limb gets its own
+// wave of the block and the group's remaining bodies ("stem") another:
+//   phase 1   stems and limb-less groups: forward
+//   phase 2   limbs: forward (parent's v, a from the shared LDS image)  |  limb-less groups: backward
+//   phase 3   limbs: backward, X^T f of the limb's root parked for the parent  |  other waves stream v out
+//   phase 4   stems: parked limb forces added, backward                  |  other waves stream a out
+//   phase 5   every wave: f and c out
+// Atlas: 6 + 7 + 7 + 4 = 24 serial body steps instead of 36, and two thirds of the output leave while the
+// backward passes run: at B = 16 384 (one block per CU, so no other block to overlap with) the launch was
+// 6 us of recursion followed by 6 us of stores at HBM speed.  v, a, f have an LDS image each.
+// ---------------------------------------------------------------------------------------------
+constexpr int LIMB_MIN = 4;
+constexpr int big_children(int p) {
+  int k = 0;
+  for (int j = 0; j < N; ++j) k += (PARENT[j] == p && subtree_size(j) >= LIMB_MIN) ? 1 : 0;
+  return k;
+}
+constexpr bool limb_candidate(int j) { return PARENT[j] >= 0 && subtree_size(j) >= LIMB_MIN && big_children(PARENT[j]) >= 2; }
+constexpr bool limb_head(int j) {           // outermost candidates only: a limb is not split again
+  if (!limb_candidate(j)) return false;
+  for (int x = PARENT[j]; x >= 0; x = PARENT[x])
+    if (limb_candidate(x)) return false;
+  return true;
+}
+constexpr int limb_of(int j) {              // head of the limb body j belongs to, -1: a stem body
+  for (int x = j; x >= 0; x = PARENT[x])
+    if (limb_head(x)) return x;
+  return -1;
+}
+constexpr bool seg_head(int j) { return PARENT[j] == -1 || limb_head(j); }
+constexpr bool seg_has(int h, int j) { return limb_head(h) ? limb_of(j) == h : (root_of(j) == h && limb_of(j) == -1); }
+constexpr int seg_index(int h) {
+  int k = 0;
+  for (int x = 0; x < h; ++x) k += seg_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int n_segs() {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += seg_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int n_limbs() {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += limb_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int limb_index(int h) {
+  int k = 0;
+  for (int x = 0; x < h; ++x) k += limb_head(x) ? 1 : 0;
+  return k;
+}
+constexpr bool stem_has_limbs(int h) {      // h: a root
+  for (int x = 0; x < N; ++x)
+    if (limb_head(x) && root_of(x) == h) return true;
+  return false;
+}
+constexpr int RS_WAVES = n_segs();
+// rank of segment h among the waves that stream v out in phase 3 (every segment but the limbs; STEMS = false)
+// or a out in phase 4 (every segment but the stems that wait for limbs; STEMS = true)
+template <bool STEMS>
+constexpr int seg_rank(int h) {
+  int k = 0;
+  for (int x = 0; x < h; ++x) {
+    if (!seg_head(x)) continue;
+    const bool out = STEMS ? (PARENT[x] == -1 && stem_has_limbs(x)) : limb_head(x);
+    k += out ? 0 : 1;
+  }
+  return k;
+}
+constexpr int n_busy_stems() {             // stems that wait for limbs: the waves that work in phase 3
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += (PARENT[x] == -1 && stem_has_limbs(x)) ? 1 : 0;
+  return k;
+}
+constexpr int RS_PARK = 7;                  // 6 scalars per (limb, configuration), odd stride
+template <class T>
+constexpr size_t rnea_segs_lds() {
+  return sizeof(T) * 64 * ((size_t)3 * odd_pad<6 * N>() + odd_pad<N>() + (size_t)(n_limbs() > 0 ? n_limbs() : 1) * RS_PARK);
+}
+template <class T>
+constexpr bool rnea_segs_ok() { return n_limbs() >= 2 && RS_WAVES <= 8 && rnea_segs_lds<T>() <= 156 * 1024; }
+
+template <class T, bool HAS_QDD>
+__global__ __launch_bounds__(64 * RS_WAVES) void rnea_segments_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+                                                                     const T* __restrict__ qdd, T grav, long long B,
+                                                                     T* __restrict__ c_out, T* __restrict__ v_out,
+                                                                     T* __restrict__ a_out, T* __restrict__ f_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int K6 = 6 * N, KP6 = odd_pad<K6>(), KPN = odd_pad<N>(), NT = 64 * RS_WAVES;
+  T* tileV = reinterpret_cast<T*>(smem_raw);          // [64][KP6]  v
+  T* tileA = tileV + 64 * KP6;                        // [64][KP6]  a
+  T* tileF = tileA + 64 * KP6;                        // [64][KP6]  accumulated f
+  T* tileC = tileF + 64 * KP6;                        // [64][KPN]  c
+  T* park = tileC + 64 * KPN;                         // [limb][64][RS_PARK]  X^T f of a limb's root, for its parent
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const long long cfg0 = (long long)blockIdx.x * 64;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < 64 ? (int)rem : 64;
+  const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
+  T* myV = tileV + lane * KP6;
+  T* myA = tileA + lane * KP6;
+  T* myF = tileF + lane * KP6;
+  T* myC = tileC + lane * KPN;
+
+  JTrig<T> tr[N];
+  T f[N][6];
+  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  // forward pass over the bodies of segment H (:569-596); a limb takes its parent's v, a from the images
+  auto forward = [&](auto H) {
+    constexpr int h = decltype(H)::value;
+    T qv[N], qdv[N], qddv[N];
+    sfor<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (seg_has(h, j)) {
+        qv[j] = q[b * N + j];
+        qdv[j] = qd[b * N + j];
+        if constexpr (HAS_QDD) qddv[j] = qdd[b * N + j]; else qddv[j] = T(0);
+      }
+    });
+    sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j)) tr[j] = make_trig<j>(qv[j]); });
+    T v[N][6], a[N][6];
+    sfor<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      if constexpr (seg_has(h, j)) {
+        T xv[6], xa[6];
+        if constexpr (p < 0) {
+          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
+        } else if constexpr (!seg_has(h, p)) {          // the limb's root: its parent lives in the stem's wave
+          T vp[6], ap[6];
+          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; vp[r] = myV[r * N + p]; ap[r] = myA[r * N + p]; });
+          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, vp, ap, xv, xa, v[j], a[j], f[j]);
+        } else {
+          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
+        }
+        sfor<0, 6>([&](auto R) {       // reference layout (6, NB): element [r][j]
+          constexpr int r = decltype(R)::value;
+          myV[r * N + j] = v[j][r];
+          myA[r * N + j] = a[j][r];
+        });
+        pin6(f[j]);                    // keep the bodies in program order (bounds the live v / a set)
+      }
+    });
+  };
+  // backward pass over the bodies of segment H (:607-619)
+  auto backward = [&](auto H) {
+    constexpr int h = decltype(H)::value;
+    sfor_down<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      if constexpr (seg_has(h, j)) {
+        myC[j] = S_dot<j>(f[j]);
+        if constexpr (p >= 0) {
+          T t[6];
+          xform_T<j>(tr[j], f[j], t);
+          if constexpr (seg_has(h, p)) {
+            sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+          } else {                                        // limb root -> parked for the stem
+            constexpr int li = limb_index(h);           // (bound to a constant: a constexpr call in a run-time expression is not folded)
+            T* pk = park + (li * 64 + lane) * RS_PARK;
+            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; pk[r] = t[r]; });
+          }
+        }
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; myF[r * N + j] = f[j][r]; });
+      }
+    });
+  };
+  // Every wave walks its own segment's timeline (same number of barriers on every path): kept as ONE branch
+  // per wave so that a segment's registers (its f and sin / cos across the phases) are not live through the
+  // code of the other segments -- phase-by-phase dispatch had put the whole block's state into one wave's
+  // register file (256 VGPRs and spills instead of 111).
+  constexpr int NT3 = 64 * (RS_WAVES - n_limbs()), NT4 = 64 * (RS_WAVES - n_busy_stems());
+  sfor<0, N>([&](auto H) {
+    constexpr int h = decltype(H)::value;
+    if constexpr (seg_head(h)) {
+      constexpr int si = seg_index(h);
+      constexpr bool limb = limb_head(h);
+      constexpr bool stem = !limb && stem_has_limbs(h);
+      constexpr int rank3 = seg_rank<false>(h), rank4 = seg_rank<true>(h);   // among the waves that stream in phase 3 / 4
+      if (wave == si) {
+        if constexpr (!limb) forward(H);                                          // phase 1
+        __syncthreads();
+        if constexpr (limb) forward(H);                                           // phase 2
+        else if constexpr (!stem) backward(H);
+        __syncthreads();
+        if constexpr (limb) backward(H);                                          // phase 3
+        else flush_tile_nt<K6, NT3>(tileV, v_out + cfg0 * K6, rank3 * 64 + lane, nvalid);
+        __syncthreads();
+        if constexpr (stem) {                                                     // phase 4
+          sfor_down<0, N>([&](auto L) {       // descending, the order in which the reference's loop adds them (:618)
+            constexpr int l = decltype(L)::value;
+            if constexpr (limb_head(l) && root_of(l) == h) {
+              constexpr int li = limb_index(l), pl = PARENT[l];
+              const T* pk = park + (li * 64 + lane) * RS_PARK;
+              sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; f[pl][r] += pk[r]; });
+            }
+          });
+          backward(H);
+        } else {
+          flush_tile_nt<K6, NT4>(tileA, a_out + cfg0 * K6, rank4 * 64 + lane, nvalid);
+        }
+      }
+    }
+  });
+  __syncthreads();
+  // ---- phase 5: f and c --------------------------------------------------------------------------------------
+  flush_tile_nt<K6, NT>(tileF, f_out + cfg0 * K6, tid, nvalid);
+  if (c_out != nullptr) flush_tile_nt<N, NT>(tileC, c_out + cfg0 * N, tid, nvalid);
 }
 
 #endif  // RBD_NEED_RNEA (group waves)
@@ -1388,6 +1605,25 @@ int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* 
   const size_t lds = rnea_lds_bytes<T>(true);
   const size_t lds_c = rnea_lds_bytes<T>(false);
   int rc;
+  if constexpr (rnea_segs_ok<T>()) {
+    // one wave per segment (stem / limb / limb-less group): Atlas fp32 B = 16 384
+    const int ropt = rbd_option(RBD_OPT_RNEA_KERNEL);
+    if (vaf && !fpass_only && ropt != RBD_RNEA_KERNEL_BATCH && ropt != RBD_RNEA_KERNEL_GROUPS) {
+      constexpr size_t ldss = rnea_segs_lds<T>();
+      if (qdd) {
+        auto k = rnea_segments_kernel<T, true>;
+        if ((rc = ensure_lds(k, ldss)) != 0) return rc;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RS_WAVES), ldss, s, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+      } else {
+        auto k = rnea_segments_kernel<T, false>;
+        if ((rc = ensure_lds(k, ldss)) != 0) return rc;
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * RS_WAVES), ldss, s, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+      }
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return hip_fail(e, "rbd_rnea (segment waves) launch");
+      return 0;
+    }
+  }
   if constexpr (rnea_groups_ok<T>()) {
     // one wave per independent root group: faster than one lane per configuration at every batch size
     // measured (Atlas fp32: 17.4 -> 13.5 us at B = 16 384, 235 -> 167 us at B = 262 144; quadruped fp32
@@ -1439,6 +1675,23 @@ int rnea_bpass_launch(const T* q, T* f, int64_t B, T* c, void* stream) {
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, f, (long long)B, c);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_rnea_bpass launch");
+  return 0;
+}
+
+// the kernel rbd_rnea launches when v, a, f are requested (c alone is always the one-lane kernel)
+template <class T>
+int rnea_kernel_name(int64_t, char* buf, size_t len) {
+  using namespace rbdk;
+  const char* t = sizeof(T) == 4 ? "float" : "double";
+  const int ropt = rbd_option(RBD_OPT_RNEA_KERNEL);
+  bool done = false;
+  if constexpr (rnea_segs_ok<T>()) {
+    if (!done && ropt != RBD_RNEA_KERNEL_BATCH && ropt != RBD_RNEA_KERNEL_GROUPS) { std::snprintf(buf, len, "rnea_segments_kernel<%s>", t); done = true; }
+  }
+  if constexpr (rnea_groups_ok<T>()) {
+    if (!done && ropt != RBD_RNEA_KERNEL_BATCH) { std::snprintf(buf, len, "rnea_groups_kernel<%s>", t); done = true; }
+  }
+  if (!done) std::snprintf(buf, len, "rnea_kernel<%s>", t);
   return 0;
 }
 
@@ -1853,6 +2106,14 @@ __attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f32(int64_t B, ch
 __attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f32(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f64(int64_t B, char* buf, size_t len);
+#ifdef RBD_TU_RNEA_F32
+int rbd_rnea_kernel_name_f32(int64_t B, char* buf, size_t len) { return rnea_kernel_name<float>(B, buf, len); }
+#endif
+#ifdef RBD_TU_RNEA_F64
+int rbd_rnea_kernel_name_f64(int64_t B, char* buf, size_t len) { return rnea_kernel_name<double>(B, buf, len); }
+#endif
 #ifdef RBD_TU_GRAD_F32
 int rbd_grad_kernel_name_f32(int64_t B, char* buf, size_t len) { return grad_kernel_name<float>(B, buf, len); }
 #endif
@@ -1886,9 +2147,7 @@ int rbd_kernel_name(int op, int elem_size, int64_t B, char* buf, size_t len) {
   if (!buf || len == 0 || (elem_size != 4 && elem_size != 8)) return fail(RBD_ERR_ARG, "rbd_kernel_name: bad arguments");
   switch (op) {
     case RBD_OP_RNEA:
-      std::snprintf(buf, len, "rnea_kernel<%s,*,*> | rnea_groups_kernel<%s,*> (small batches of multi-root robots)",
-                    elem_size == 4 ? "float" : "double", elem_size == 4 ? "float" : "double");
-      return 0;
+      return elem_size == 4 ? rbd_rnea_kernel_name_f32(B, buf, len) : rbd_rnea_kernel_name_f64(B, buf, len);
     case RBD_OP_RNEA_GRAD:
       return elem_size == 4 ? rbd_grad_kernel_name_f32(B, buf, len) : rbd_grad_kernel_name_f64(B, buf, len);
     case RBD_OP_MINV:

@@ -80,19 +80,47 @@ def test_library_loaded_is_the_hip_one(name):
 
 
 @pytest.mark.parametrize("name", all_golden_names())
-@pytest.mark.parametrize("rnea_kernel", ["batch", "groups"])
+@pytest.mark.parametrize("rnea_kernel", ["batch", "groups", "auto"])
 def test_rnea_vs_golden(name, prec, rnea_kernel):
-    """Both rnea kernels: one lane per configuration, and one wave per independent root subtree (what AUTO
-    picks for small batches of robots with several roots; a robot without such groups ignores the option)."""
+    """Every rnea kernel: one lane per configuration, one wave per independent root subtree, and AUTO's choice
+    (Atlas: one wave per stem / limb / root subtree; a robot without groups or limbs ignores the option)."""
     from rbdreference_amd._lib import (RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO, RBD_RNEA_KERNEL_BATCH,
                                        RBD_RNEA_KERNEL_GROUPS)
     dt, tol = prec
     g = load_golden(name); rbd = rbd_for(name)
-    rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_BATCH if rnea_kernel == "batch" else RBD_RNEA_KERNEL_GROUPS)
+    rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, {"batch": RBD_RNEA_KERNEL_BATCH, "groups": RBD_RNEA_KERNEL_GROUPS,
+                                              "auto": RBD_RNEA_KERNEL_AUTO}[rnea_kernel])
     try:
         _rnea_vs_golden(rbd, g, dt, tol)
     finally:
         rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO)
+
+
+@pytest.mark.parametrize("B", [1, 63, 200])
+def test_atlas_rnea_segment_waves_ragged(B):
+    """The segment-wave kernel (AUTO on Atlas, fp32) on ragged batches against the oracle, and against the
+    one-lane-per-configuration kernel: same recursion, other summation order of the limb forces at most."""
+    from rbdreference_amd._lib import RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO, RBD_RNEA_KERNEL_BATCH
+    name = "atlas_like"
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    rbd = rbd_for(name); om = orc.model_from_robot(make_robot(name))
+    rng = np.random.default_rng(77 + B)
+    q = rng.uniform(-np.pi, np.pi, (B, rbd.n)); qd = rng.uniform(-1, 1, (B, rbd.n)); qdd = rng.uniform(-1, 1, (B, rbd.n))
+    tq, tqd, tqdd = dev_tensors(torch.float32, q, qd, qdd)
+    assert "rnea_segments_kernel" in rbd._lib.kernel_name(0, 4, B)
+    got = rbd.rnea(tq, tqd, tqdd)
+    rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_BATCH)
+    try:
+        base = rbd.rnea(tq, tqd, tqdd)
+    finally:
+        rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO)
+    want = orc.rnea(om, q, qd, qdd)
+    for nm, x, y, w in zip("cvaf", got, base, want):
+        check(nm, x, w, TOL32)
+        check(nm + " vs batch kernel", x, y.double().cpu().numpy(), 1e-6)
+    got0 = rbd.rnea(tq, tqd)
+    check("c_noqdd", got0[0], orc.rnea(om, q, qd)[0], TOL32)
 
 
 def _rnea_vs_golden(rbd, g, dt, tol):
