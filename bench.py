@@ -420,6 +420,24 @@ def main():
                 ms = time_extra_ms(lambda: ra.rnea(qa, qda, qdda), 20, 3)
                 extra["cfg2_atlas_rnea_cvaf_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
                                                             "alg_GBps": 16384 * 2640 / (ms * 1e-3) / 1e9}
+                # the same two entry points through the C-ABI with pre-allocated outputs (what a host that owns
+                # its buffers pays: the per-call numbers above include four / one torch allocations)
+                Ba, na = 16384, 30
+                ca = torch.empty((Ba, na), device=dev, dtype=torch.float32)
+                va = torch.empty((Ba, 6, na), device=dev, dtype=torch.float32); aa = torch.empty_like(va); fa = torch.empty_like(va)
+                Ma = torch.empty((Ba, na, na), device=dev, dtype=torch.float32)
+                wsb = int(ra._lib.lib.rbd_minv_workspace_bytes(Ba, 4))
+                wsa = torch.empty((max(wsb, 16),), device=dev, dtype=torch.uint8)
+                st = torch.cuda.current_stream(dev).cuda_stream
+                f_rnea = ra._fn("rbd_rnea", torch.float32); f_minv = ra._fn("rbd_minv", torch.float32)
+                ms = time_extra_ms(lambda: f_rnea(qa.data_ptr(), qda.data_ptr(), qdda.data_ptr(), -9.81, Ba, ca.data_ptr(),
+                                                  va.data_ptr(), aa.data_ptr(), fa.data_ptr(), st), 100, 10)
+                extra["cfg2_atlas_rnea_cvaf_B16384_f32"].update(ms_per_launch_abi=ms, alg_GBps_abi=Ba * 2640 / (ms * 1e-3) / 1e9,
+                                                                kernel=ra._lib.kernel_name(0, 4, Ba))
+                ms = time_extra_ms(lambda: f_minv(qa.data_ptr(), Ba, 1, Ma.data_ptr(), wsa.data_ptr(), wsb, st), 100, 10)
+                extra["cfg2_atlas_minv_B16384_f32"].update(ms_per_launch_abi=ms, alg_GBps_abi=Ba * 3720 / (ms * 1e-3) / 1e9,
+                                                           kernel=ra._lib.kernel_name(2, 4, Ba))
+                del ca, va, aa, fa, Ma, wsa
                 ms = time_extra_ms(lambda: ra.rnea_grad(qa, qda, qdda, return_c=True), 20, 3)
                 extra["atlas_rnea_grad_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
                                                        "alg_GBps": 16384 * (4 * 30 + 2 * 900) * 4 / (ms * 1e-3) / 1e9}
@@ -430,6 +448,19 @@ def main():
                 extra["cfg4_quadruped_rnea_grad+minv_B65536_f64"] = {
                     "ms_rnea_grad": ms1, "ms_minv": ms2, "evals_per_s": 65536 / ((ms1 + ms2) * 1e-3),
                     "alg_GBps": 65536 * 3840 / ((ms1 + ms2) * 1e-3) / 1e9}
+                # floating base: a 13-body trunk + four legs, nv = 18, fp32
+                from rbdreference_amd import floating_quadruped_like
+                rf = RBDReference(floating_quadruped_like(), build=False)
+                Bf = 65536
+                qf, qdf, qddf = make_inputs(Bf, rf.nv, 5, dev)
+                nvf, nbf = rf.nv, rf.n
+                t1 = time_extra_ms(lambda: rf.rnea(qf, qdf, qddf), 10, 2)
+                t2 = time_extra_ms(lambda: rf.minv(qf), 10, 2)
+                t3 = time_extra_ms(lambda: rf.rnea_grad(qf, qdf, qddf, return_c=True), 5, 1)
+                extra["floating_quadruped_B65536_f32"] = {
+                    "ms_rnea_cvaf": t1, "alg_GBps_rnea": Bf * (4 * nvf + 18 * nbf) * 4 / (t1 * 1e-3) / 1e9,
+                    "ms_minv": t2, "alg_GBps_minv": Bf * (nvf + nvf * nvf) * 4 / (t2 * 1e-3) / 1e9,
+                    "ms_rnea_grad": t3, "alg_GBps_rnea_grad": Bf * (4 * nvf + 2 * nvf * nvf) * 4 / (t3 * 1e-3) / 1e9}
             except Exception as e:  # the headline line must still be printed
                 extra["error"] = repr(e)
             out["extra"] = extra

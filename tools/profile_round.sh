@@ -16,6 +16,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_
   tag=$(echo $pass | cut -d' ' -f1)
   REPS=6 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_cfg_$tag -- python3 tools/run_configs.py atlas iiwa4k > $OUT/pmc_cfg_$tag.log 2>&1 || echo "pmc cfg $tag failed"
 done
+bash tools/pmc_stalls.sh ${1:-prof}/stalls > $OUT/pmc_stalls.log 2>&1 || echo "pmc stalls failed"
 mkdir -p $OUT/head $OUT/cfg
 python3 tools/pmc_summary.py $OUT rnea_grad_idsva > $OUT/pmc_head_summary.json
 for d in $OUT/pmc_cfg_*; do :; done
