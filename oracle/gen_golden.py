@@ -163,6 +163,9 @@ def main():
     # two roots whose subtrees INTERLEAVE in the numbering (0: {0,2,4,5,7}, 1: {1,3,6}) and a branch
     robots.append(("random_forest_n8", random_tree([-1, -1, 0, 1, 2, 0, 3, 5], seed=33,
                                                     name="random_forest_n8"), 204))
+    # one root, a two-body stem and three four-body limbs under its second body (segment-wave kernels)
+    robots.append(("random_limbs_n14", random_tree([-1, 0, 1, 2, 3, 4, 1, 6, 7, 8, 1, 10, 11, 12], seed=41,
+                                                    name="random_limbs_n14"), 205))
     only = set(sys.argv[1:])
     for nm, robot, seed in fb_robots():
         if only and nm not in only:

@@ -24,8 +24,9 @@ namespace rbdk {
 constexpr int gc_lanes() { return 2 * N <= 8 ? 8 : 2 * N <= 16 ? 16 : 2 * N <= 32 ? 32 : 64; }
 // a lane keeps the accumulated f and the df of every body for its backward pass (12 n scalars) beside
 // the running v, a, dv, da: built for the robots where that fits the 512-register file of a lone wave
+// (a dense 14-body tree already spills 280 bytes in fp32)
 template <class T>
-constexpr bool grad_cols_ok() { return N <= (sizeof(T) == 4 ? 16 : 6); }
+constexpr bool grad_cols_ok() { return N <= (sizeof(T) == 4 ? 12 : 6); }
 constexpr int GC_L = gc_lanes();            // lanes per configuration
 constexpr int GC_CPW = 64 / GC_L;           // configurations per wave
 // LDS: per configuration slot the image of (v, a, f, c) = 18 n + n scalars, padded to 16 bytes

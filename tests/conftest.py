@@ -56,6 +56,8 @@ def make_robot(name):
         return random_tree([-1, 0, 1, 2, 3, 4, 5], seed=21, name=name)
     if name == "random_prismatic_n6":
         return random_tree([-1, 0, 1, 2, 2, 4], seed=11, prismatic_every=3, name=name)
+    if name == "random_limbs_n14":      # one root, three 4-body limbs under body 1 (segment waves)
+        return random_tree([-1, 0, 1, 2, 3, 4, 1, 6, 7, 8, 1, 10, 11, 12], seed=41, name=name)
     if name == "random_forest_n8":      # interleaved root subtrees + a branch (no per-root groups)
         return random_tree([-1, -1, 0, 1, 2, 0, 3, 5], seed=33, name=name)
     raise KeyError(name)

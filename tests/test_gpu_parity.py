@@ -96,12 +96,13 @@ def test_rnea_vs_golden(name, prec, rnea_kernel):
         rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO)
 
 
+@pytest.mark.parametrize("name", ["atlas_like", "random_limbs_n14"])
 @pytest.mark.parametrize("B", [1, 63, 200])
-def test_atlas_rnea_segment_waves_ragged(B):
-    """The segment-wave kernel (AUTO on Atlas, fp32) on ragged batches against the oracle, and against the
+def test_rnea_segment_waves_ragged(name, B):
+    """The segment-wave kernel (AUTO on Atlas: stem + two arms + two limb-less legs; on the 14-body tree: one
+    root, a two-body stem and three limbs; fp32) on ragged batches against the oracle, and against the
     one-lane-per-configuration kernel: same recursion, other summation order of the limb forces at most."""
     from rbdreference_amd._lib import RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO, RBD_RNEA_KERNEL_BATCH
-    name = "atlas_like"
     from oracle import rbd_oracle as orc
     torch = _torch()
     rbd = rbd_for(name); om = orc.model_from_robot(make_robot(name))
