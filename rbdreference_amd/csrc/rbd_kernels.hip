@@ -18,7 +18,8 @@
 //               accumulated in registers and parked once in the LDS image of the output tile.
 //   minv        minv_lane_kernel (rbd_minv_lane.h): one lane per configuration, fused, for robots with
 //               small root groups; otherwise phase A (minv_ia_kernel / minv_ia8_kernel) + phase B
-//               (minv_cols_kernel, one lane per COLUMN) through a [body][config][12] workspace.
+//               (minv_cols_kernel, one lane per COLUMN, one wave per column class of a group with limbs)
+//               through a [body][config][12] workspace; minv_ia8_kernel also finishes the groups of <= 8 bodies.
 //   crba, rnea_fpass / rnea_bpass, forward_dynamics(_grad): further rows, same building blocks.
 // The library is built from several translation units of this one file (rbdreference_amd/build.py
 // compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
@@ -398,6 +399,88 @@ constexpr int n_groups() {
   for (int x = 0; x < N; ++x) k += grp_head(x) ? 1 : 0;
   return k;
 }
+
+// ---- segments: big sibling subtrees of a root subtree ("limbs": Atlas' two arms under the third back joint)
+// and what is left of it ("stem").  Limbs are independent of each other between their parent's forward
+// quantities and what they hand back to it, so kernels for small batches give each its own wave.
+constexpr int LIMB_MIN = 4;
+// evaluated ONCE into a table (the queries below are used inside nested constexpr loops; recomputed from the
+// parent array every time they exceed the compiler's constant-evaluation step limit at n = 30)
+struct LimbTable {
+  int limb_of[N];      // head of the limb body j belongs to, -1: a stem body
+  bool head[N];
+};
+constexpr LimbTable make_limb_table() {
+  LimbTable t{};
+  int size[N] = {};
+  for (int j = N - 1; j >= 0; --j) {        // parents precede children: one reverse pass gives the subtree sizes
+    size[j] += 1;
+    if (PARENT[j] >= 0) size[PARENT[j]] += size[j];
+  }
+  bool cand[N] = {};
+  for (int j = 0; j < N; ++j) {
+    int big = 0;
+    if (PARENT[j] >= 0)
+      for (int x = 0; x < N; ++x) big += (PARENT[x] == PARENT[j] && size[x] >= LIMB_MIN) ? 1 : 0;
+    cand[j] = PARENT[j] >= 0 && size[j] >= LIMB_MIN && big >= 2;
+  }
+  for (int j = 0; j < N; ++j) {             // outermost candidates only: a limb is not split again
+    const int p = PARENT[j];
+    const int up = p >= 0 ? t.limb_of[p] : -1;
+    t.head[j] = cand[j] && up == -1;
+    t.limb_of[j] = up != -1 ? up : (t.head[j] ? j : -1);
+  }
+  return t;
+}
+constexpr LimbTable LIMBS = make_limb_table();
+constexpr bool limb_head(int j) { return LIMBS.head[j]; }
+constexpr int limb_of(int j) { return LIMBS.limb_of[j]; }
+constexpr bool seg_head(int j) { return PARENT[j] == -1 || limb_head(j); }
+constexpr bool seg_has(int h, int j) { return limb_head(h) ? limb_of(j) == h : (root_of(j) == h && limb_of(j) == -1); }
+constexpr int seg_index(int h) {
+  int k = 0;
+  for (int x = 0; x < h; ++x) k += seg_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int n_segs() {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += seg_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int n_limbs() {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += limb_head(x) ? 1 : 0;
+  return k;
+}
+constexpr int limb_index(int h) {
+  int k = 0;
+  for (int x = 0; x < h; ++x) k += limb_head(x) ? 1 : 0;
+  return k;
+}
+constexpr bool stem_has_limbs(int h) {      // h: a root
+  for (int x = 0; x < N; ++x)
+    if (limb_head(x) && root_of(x) == h) return true;
+  return false;
+}
+constexpr int limbs_of_root(int rt) {
+  int k = 0;
+  for (int x = 0; x < N; ++x) k += (limb_head(x) && root_of(x) == rt) ? 1 : 0;
+  return k;
+}
+constexpr int max_limbs_per_root() {
+  int m = 0;
+  for (int x = 0; x < N; ++x)
+    if (PARENT[x] == -1 && limbs_of_root(x) > m) m = limbs_of_root(x);
+  return m;
+}
+constexpr int kth_limb(int rt, int k) {     // head of the k-th limb (k = 0, 1, ...) of root subtree rt, -1 if none
+  for (int x = 0; x < N; ++x)
+    if (limb_head(x) && root_of(x) == rt) {
+      if (k == 0) return x;
+      --k;
+    }
+  return -1;
+}
 constexpr int grad_max_rows() {
   int m = 0;
   for (int r = 0; r < N; ++r)
@@ -556,51 +639,6 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rnea_groups_kernel(const T* __r
 // backward passes run: at B = 16 384 (one block per CU, so no other block to overlap with) the launch was
 // 6 us of recursion followed by 6 us of stores at HBM speed.  v, a, f have an LDS image each.
 // ---------------------------------------------------------------------------------------------
-constexpr int LIMB_MIN = 4;
-constexpr int big_children(int p) {
-  int k = 0;
-  for (int j = 0; j < N; ++j) k += (PARENT[j] == p && subtree_size(j) >= LIMB_MIN) ? 1 : 0;
-  return k;
-}
-constexpr bool limb_candidate(int j) { return PARENT[j] >= 0 && subtree_size(j) >= LIMB_MIN && big_children(PARENT[j]) >= 2; }
-constexpr bool limb_head(int j) {           // outermost candidates only: a limb is not split again
-  if (!limb_candidate(j)) return false;
-  for (int x = PARENT[j]; x >= 0; x = PARENT[x])
-    if (limb_candidate(x)) return false;
-  return true;
-}
-constexpr int limb_of(int j) {              // head of the limb body j belongs to, -1: a stem body
-  for (int x = j; x >= 0; x = PARENT[x])
-    if (limb_head(x)) return x;
-  return -1;
-}
-constexpr bool seg_head(int j) { return PARENT[j] == -1 || limb_head(j); }
-constexpr bool seg_has(int h, int j) { return limb_head(h) ? limb_of(j) == h : (root_of(j) == h && limb_of(j) == -1); }
-constexpr int seg_index(int h) {
-  int k = 0;
-  for (int x = 0; x < h; ++x) k += seg_head(x) ? 1 : 0;
-  return k;
-}
-constexpr int n_segs() {
-  int k = 0;
-  for (int x = 0; x < N; ++x) k += seg_head(x) ? 1 : 0;
-  return k;
-}
-constexpr int n_limbs() {
-  int k = 0;
-  for (int x = 0; x < N; ++x) k += limb_head(x) ? 1 : 0;
-  return k;
-}
-constexpr int limb_index(int h) {
-  int k = 0;
-  for (int x = 0; x < h; ++x) k += limb_head(x) ? 1 : 0;
-  return k;
-}
-constexpr bool stem_has_limbs(int h) {      // h: a root
-  for (int x = 0; x < N; ++x)
-    if (limb_head(x) && root_of(x) == h) return true;
-  return false;
-}
 constexpr int RS_WAVES = n_segs();
 // rank of segment h among the waves that stream v out in phase 3 (every segment but the limbs; STEMS = false)
 // or a out in phase 4 (every segment but the stems that wait for limbs; STEMS = true)
@@ -1220,20 +1258,76 @@ constexpr int minv_ts(int rt) { return minv_vec_flush(rt) ? grp_rows(rt) * N + 4
 // groups' columns are structural zeros, generated at the flush (9.1 -> 6.5 KB per Atlas torso block: 6
 // instead of 4 waves per SIMD)
 constexpr int minv_tso(int rt) { return grp_rows(rt) * grp_rows(rt) + ((grp_rows(rt) * grp_rows(rt)) % 2 == 0 ? 1 : 0); }
+// Waves per block of the column phase.  Root subtrees with limbs (Atlas' torso) give every column CLASS its own
+// wave -- class 0: the stem's columns, class k: the columns of the k-th limb -- because a class needs only part
+// of the bodies: backward sweep = the bodies with a class column in their subtree (a limb's own bodies and
+// its stem ancestors), forward sweep = the bodies up to the class' last column (rows i <= j of the upper
+// triangle; what lies below is mirrored).  Atlas torso, per 9 configurations: 8 + 21 + 28 wave-steps (stem,
+// left arm, right arm) instead of 3 x 36.  The waves of a block share the records and the tile.  In limb-less
+// groups the waves of a block are independent (each its own configurations and LDS region).
+constexpr int MINV_COLS_W = GRAD_PER_ROOT ? 1 + max_limbs_per_root() : 1;
+constexpr int mcl_limbs(int rt) { return GRAD_PER_ROOT ? limbs_of_root(rt) : 0; }
+constexpr bool mcl_has(int rt, int cls, int j) {     // column j belongs to class cls of root subtree rt
+  if (root_of(j) != rt) return false;
+  return cls == 0 ? limb_of(j) == -1 : limb_of(j) == kth_limb(rt, cls - 1);
+}
+constexpr int mcl_count(int rt, int cls) {
+  int k = 0;
+  for (int j = 0; j < N; ++j) k += mcl_has(rt, cls, j) ? 1 : 0;
+  return k;
+}
+constexpr int mcl_col(int rt, int cls, int k) {      // k-th column of the class
+  for (int j = 0; j < N; ++j)
+    if (mcl_has(rt, cls, j)) {
+      if (k == 0) return j;
+      --k;
+    }
+  return -1;
+}
+constexpr int mcl_max(int rt, int cls) {
+  int m = -1;
+  for (int j = 0; j < N; ++j)
+    if (mcl_has(rt, cls, j)) m = j;
+  return m;
+}
+constexpr bool mcl_bwd(int rt, int cls, int i) {     // body i takes part in the class' backward sweep
+  if (root_of(i) != rt) return false;
+  for (int j = 0; j < N; ++j)
+    if (mcl_has(rt, cls, j) && is_anc_or_self(i, j)) return true;
+  return false;
+}
+constexpr bool mcl_fwd(int rt, int cls, int i) { return root_of(i) == rt && i <= mcl_max(rt, cls); }
+constexpr int mcl_cpb(int rt) {                      // configurations per block of a group with limbs
+  int m = 64;
+  for (int c = 0; c <= mcl_limbs(rt); ++c) {
+    const int x = 64 / mcl_count(rt, c);
+    m = x < m ? x : m;
+  }
+  return m;
+}
+// configurations per BLOCK and LDS scalars per block of group rt
+constexpr int minv_cfgs_per_block(int rt) { return mcl_limbs(rt) > 0 ? mcl_cpb(rt) : minv_cpb(rt) * MINV_COLS_W; }
+constexpr size_t minv_wave_scalars(int rt) { return (size_t)minv_cpb(rt) * minv_tso(rt) + (size_t)minv_cpb(rt) * grp_rows(rt) * MINV_WS; }
+constexpr size_t minv_block_scalars(int rt) {
+  return mcl_limbs(rt) > 0 ? (size_t)mcl_cpb(rt) * minv_tso(rt) + (size_t)mcl_cpb(rt) * grp_rows(rt) * MINV_WS
+                           : minv_wave_scalars(rt) * MINV_COLS_W;
+}
 template <class T>
 constexpr size_t minv_cols_lds_bytes() {
   size_t m = 0;
   for (int rt = 0; rt < N; ++rt)
     if (grp_head(rt)) {
-      const size_t x = sizeof(T) * ((size_t)minv_cpb(rt) * minv_tso(rt) + (size_t)minv_cpb(rt) * grp_rows(rt) * MINV_WS);
+      const size_t x = sizeof(T) * ((minv_block_scalars(rt) + 3) / 4 * 4);
       m = x > m ? x : m;
     }
   return m;
 }
-inline long long minv_cols_blocks(long long B) {
+// groups of at most 8 bodies are finished by minv_ia8_kernel when it runs as phase A (rbd_minv_ia8.h)
+constexpr bool minv_small_grp(int rt) { return GRAD_PER_ROOT && grp_rows(rt) <= 8; }
+inline long long minv_cols_blocks(long long B, bool skip_small) {
   long long nb = 0;
   for (int rt = 0; rt < N; ++rt)
-    if (grp_head(rt)) nb += (B + minv_cpb(rt) - 1) / minv_cpb(rt);
+    if (grp_head(rt) && !(skip_small && minv_small_grp(rt))) nb += (B + minv_cfgs_per_block(rt) - 1) / minv_cfgs_per_block(rt);
   return nb;
 }
 constexpr unsigned long long subtree_mask(int i) {
@@ -1248,9 +1342,13 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
                              long long blk, unsigned char* smem_raw) {
   constexpr int row0 = grp_row0(RT), rows = grp_rows(RT);
   constexpr int LC = minv_lc(rows), CPB = 64 / LC, TS = minv_tso(RT);
-  T* wsl = reinterpret_cast<T*>(smem_raw);                 // [CPB][rows][MINV_WS] per-body records
+  // the waves of a block are independent here: wave w works on sub-block blk * W + w in its own LDS region
+  const int wave = threadIdx.x >> 6;
+  constexpr int WAVE_SCALARS = (int)minv_wave_scalars(RT);   // (bound to a constant: a constexpr call in a run-time expression is not folded)
+  T* wsl = reinterpret_cast<T*>(smem_raw) + wave * WAVE_SCALARS;   // [CPB][rows][MINV_WS] per-body records
   T* tile = wsl + CPB * rows * MINV_WS;                    // [CPB][TS] the group's own block [rows][rows] of Minv
-  const int lane = threadIdx.x;
+  blk = blk * MINV_COLS_W + wave;
+  const int lane = threadIdx.x & 63;
   const int slot0 = lane / LC;
   const bool spare = slot0 >= CPB;       // lanes beyond CPB * rows
   const int slot = spare ? CPB - 1 : slot0;
@@ -1258,7 +1356,7 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
   const int j = row0 + jl;               // ... and in the matrix
   const long long cfg0 = blk * CPB;
   const long long rem = B - cfg0;
-  const int nvalid = rem < CPB ? (int)rem : CPB;
+  const int nvalid = rem < CPB ? (rem > 0 ? (int)rem : 0) : CPB;   // 0: a trailing wave without configurations
 
   // stage the block's {U, 1/D, sin, cos} records in LDS once (both sweeps read them; every lane of a
   // configuration reads the same record => LDS broadcast instead of 2 x n dependent L2 round trips)
@@ -1273,7 +1371,7 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
       const int rec = idx / VPB;
       const int body = row0 + rec % rows;
       const int cs = rec / rows;
-      const long long bb = cfg0 + (cs < nvalid ? cs : nvalid - 1);
+      const long long bb = nvalid > 0 ? cfg0 + (cs < nvalid ? cs : nvalid - 1) : B - 1;
       dst[idx] = reinterpret_cast<const V*>(ws + ((long long)body * B + bb) * MINV_WS)[piece];
     }
   }
@@ -1395,10 +1493,201 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
   }
 }
 
+// next body below i (backward order) / above i (forward order) that class CLS of group RT visits, -1 if none
+constexpr int mcl_next_bwd(int rt, int cls, int i) {
+  for (int x = i - 1; x >= 0; --x)
+    if (mcl_bwd(rt, cls, x)) return x;
+  return -1;
+}
+constexpr int mcl_first_bwd(int rt, int cls) { return mcl_next_bwd(rt, cls, N); }
+constexpr int mcl_next_fwd(int rt, int cls, int i) {
+  for (int x = i + 1; x < N; ++x)
+    if (mcl_fwd(rt, cls, x)) return x;
+  return -1;
+}
+constexpr int mcl_first_fwd(int rt, int cls) { return mcl_next_fwd(rt, cls, -1); }
+
+// The two sweeps of ONE column class of a group with limbs (wave CLS of the block): same arithmetic as
+// minv_cols_group, restricted at compile time to the bodies the class needs; fills the class' columns of
+// the shared tile (and their mirror images).
+template <class T, int RT, int CLS>
+RBD_DEV void minv_cols_class(const T* wsl, T* tile, int dense, int lane, int& slot_out, int& j_out, bool& spare_out) {
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT);
+  constexpr int LC = mcl_count(RT, CLS), CPB = mcl_cpb(RT), TS = minv_tso(RT);
+  const int slot0 = lane / LC;
+  const bool spare = slot0 >= CPB;       // lanes beyond CPB * LC
+  const int slot = spare ? CPB - 1 : slot0;
+  const int kc = spare ? LC - 1 : lane - slot0 * LC;     // this lane's column within the class
+  constexpr int col0 = mcl_col(RT, CLS, 0);   // (bound to a constant first: a constexpr call in a run-time expression is not folded)
+  int j = col0;
+  sfor<1, LC>([&](auto K) { constexpr int k = decltype(K)::value; constexpr int col = mcl_col(RT, CLS, k); j = sel(kc == k, col, j); });
+  slot_out = slot; j_out = j; spare_out = spare;
+  const T* myws = wsl + (slot * rows - row0) * MINV_WS;   // myws + i * MINV_WS = record of body i
+
+  T mcol[N];
+  sfor<row0, row0 + rows>([&](auto I) { mcol[decltype(I)::value] = T(0); });   // bodies the backward sweep skips
+  T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  T rec[N][MINV_WS];
+  constexpr int b0 = mcl_first_bwd(RT, CLS);
+  ws_read_lds(myws, b0, rec[b0]);
+  // ---- backward sweep (:665-726), column j: the bodies with a class column in their subtree -----------------
+  sfor_down<row0, row0 + rows>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if constexpr (mcl_bwd(RT, CLS, i)) {
+      constexpr int p = PARENT[i];
+      constexpr unsigned long long mask = subtree_mask(i);
+      constexpr int nx = mcl_next_bwd(RT, CLS, i);
+      if constexpr (nx >= 0) ws_read_lds(myws, nx, rec[nx]);
+      BodyCfg<T> bc;
+      sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = rec[i][decltype(R)::value]; });
+      bc.Dinv = rec[i][6]; bc.s = rec[i][7]; bc.c = rec[i][8];
+      const bool insub = ((mask >> j) & 1ull) != 0;
+      T m = sel(j == i, bc.Dinv, -(bc.Dinv * S_dot<i>(Fj)));         // :700, :702-708
+      m = sel(insub, m, T(0));
+      mcol[i] = m;
+      if constexpr (p >= 0) {
+        T t[6], y[6];
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(bc.U[r], m, Fj[r]); });   // :721-723
+        const JTrig<T> g{bc.s, bc.c};
+        xform_T<i>(g, t, y);                                                                                  // :724-726
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fj[r] = sel(insub, y[r], Fj[r]); });
+      }
+      pin6(Fj);
+    }
+  });
+  // ---- forward sweep (:760-781), column j: rows i <= the class' last column ---------------------------------
+  T Ff[N][6];
+  const T* myws2 = myws;
+  T rec2[N][MINV_WS];
+  constexpr int f0 = mcl_first_fwd(RT, CLS);
+  ws_read_lds(myws2, f0, rec2[f0]);
+  sfor<row0, row0 + rows>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if constexpr (mcl_fwd(RT, CLS, i)) {
+      constexpr int p = PARENT[i];
+      constexpr int si = s_index(i);
+      constexpr int nx = mcl_next_fwd(RT, CLS, i);
+      if constexpr (nx >= 0) ws_read_lds(myws2, nx, rec2[nx]);
+      if constexpr (p < 0) {
+        sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
+        Ff[i][si] = mcol[i];                                                                        // :781
+      } else {
+        BodyCfg<T> bc;
+        sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = rec2[i][decltype(R)::value]; });
+        bc.Dinv = rec2[i][6]; bc.s = rec2[i][7]; bc.c = rec2[i][8];
+        const JTrig<T> g{bc.s, bc.c};
+        xform<i>(g, Ff[p], Ff[i]);
+        const T m = fma_(-bc.Dinv, dot6(bc.U, Ff[i]), mcol[i]);                                     // :771-773
+        mcol[i] = m;
+        Ff[i][si] += m;                                                                             // :774-776
+      }
+      pin6(Ff[i]);
+    }
+  });
+  // ---- the class' columns of the tile, mirrored (:799-804) ------------------------------------------------------
+  T* myt = tile + slot * TS;                               // myt[(i - row0) * rows + (c - row0)]
+  const int jl = j - row0;
+  if (!spare) {
+    sfor<row0, row0 + rows>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (mcl_fwd(RT, CLS, i)) {
+        if (i <= j) myt[(i - row0) * rows + jl] = mcol[i];
+        if (i < j) myt[jl * rows + (i - row0)] = sel(dense != 0, mcol[i], T(0));
+      }
+    });
+  }
+}
+
+// A group with limbs: one block = mcl_cpb(RT) configurations, one wave per column class, shared records and tile.
+template <class T, int RT>
+RBD_DEV void minv_cols_limbs(const T* __restrict__ ws, long long B, int dense, T* __restrict__ Minv,
+                             const T* __restrict__ u_in, const T* __restrict__ c_in, T* __restrict__ qdd_out,
+                             long long blk, unsigned char* smem_raw) {
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT);
+  constexpr int CPB = mcl_cpb(RT), TS = minv_tso(RT), NT = 64 * MINV_COLS_W, NL = mcl_limbs(RT);
+  T* wsl = reinterpret_cast<T*>(smem_raw);                 // [CPB][rows][MINV_WS] per-body records
+  T* tile = wsl + CPB * rows * MINV_WS;                    // [CPB][TS] the group's own block [rows][rows] of Minv
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const long long cfg0 = blk * CPB;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < CPB ? (int)rem : CPB;
+  {
+    constexpr int VE = 16 / sizeof(T);
+    constexpr int VPB = MINV_WS / VE;                      // 16-byte pieces per record
+    typedef T V __attribute__((ext_vector_type(VE)));
+    V* dst = reinterpret_cast<V*>(wsl);
+#pragma unroll 2
+    for (int idx = tid; idx < CPB * rows * VPB; idx += NT) {
+      const int piece = idx % VPB;
+      const int rec = idx / VPB;
+      const int body = row0 + rec % rows;
+      const int cs = rec / rows;
+      const long long bb = cfg0 + (cs < nvalid ? cs : nvalid - 1);
+      dst[idx] = reinterpret_cast<const V*>(ws + ((long long)body * B + bb) * MINV_WS)[piece];
+    }
+  }
+  __syncthreads();
+  int slot = 0, j = row0;
+  bool spare = true;                                       // a wave without a class in this group stays "spare"
+  sfor<0, MINV_COLS_W>([&](auto W) {
+    constexpr int w = decltype(W)::value;
+    if constexpr (w <= NL) {
+      if (wave == w) minv_cols_class<T, RT, w>(wsl, tile, dense, lane, slot, j, spare);
+    }
+  });
+  __syncthreads();
+
+  if (qdd_out != nullptr) {
+    // forward_dynamics epilogue (:1371-1374): qdd = Minv (u - c); lane j owns row j of the dense tile.
+    T* tau = wsl + slot * rows - row0;                     // tau[k], k in the group (the record area is free now)
+    if (!spare && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
+    __syncthreads();
+    if (!spare && slot < nvalid) {
+      const T* myt = tile + slot * TS + (j - row0) * rows;
+      T o = T(0);
+      sfor<row0, row0 + rows>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[k - row0], tau[k], o); });
+      qdd_out[(cfg0 + slot) * N + j] = o;
+    }
+  }
+  if (Minv != nullptr) {
+    constexpr int RW = rows * N;
+    T* gdst = Minv + cfg0 * (N * N) + row0 * N;
+    auto elem = [&](int cfg, int e) -> T {
+      const int r = e / N;
+      const int c = e - r * N - row0;
+      const bool own = c >= 0 && c < rows;
+      const T x = tile[cfg * TS + r * rows + (own ? c : 0)];
+      return own ? x : T(0);
+    };
+    if constexpr (minv_vec_flush(RT) && sizeof(T) == 4) {
+      typedef T V __attribute__((ext_vector_type(4)));
+      constexpr int RV = RW / 4;
+      const int total = nvalid * RV;
+#pragma unroll 2
+      for (int g = tid; g < total; g += NT) {
+        const int cfg = g / RV;
+        const int r4 = g - cfg * RV;
+        V x;
+        x[0] = elem(cfg, 4 * r4); x[1] = elem(cfg, 4 * r4 + 1); x[2] = elem(cfg, 4 * r4 + 2); x[3] = elem(cfg, 4 * r4 + 3);
+        reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
+      }
+    } else {
+      const int total = nvalid * RW;
+#pragma unroll 4
+      for (int g = tid; g < total; g += NT) {
+        const int cfg = g / RW;
+        const int r2 = g - cfg * RW;
+        gdst[(long long)cfg * (N * N) + r2] = elem(cfg, r2);
+      }
+    }
+  }
+}
+
 template <class T>
-__global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
+__global__ __launch_bounds__(64 * MINV_COLS_W, MINV_COLS_MIN_WAVES) void minv_cols_kernel(const T* __restrict__ ws, long long B, int dense,
                                                        T* __restrict__ Minv, const T* __restrict__ u_in,
-                                                       const T* __restrict__ c_in, T* __restrict__ qdd_out) {
+                                                       const T* __restrict__ c_in, T* __restrict__ qdd_out, int skip_small) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // 1-D grid: the blocks of group 0, then those of group 1, ... (each group has its own
   // configurations-per-block count)
@@ -1407,11 +1696,16 @@ __global__ __launch_bounds__(64, MINV_COLS_MIN_WAVES) void minv_cols_kernel(cons
   sfor<0, N>([&](auto Rt) {
     constexpr int rt = decltype(Rt)::value;
     if constexpr (grp_head(rt)) {
-      constexpr int cpb = minv_cpb(rt);   // constexpr on purpose: as a plain call the tree walk ran at run time
-      const long long nb = (B + cpb - 1) / cpb;
+      constexpr int cpb = minv_cfgs_per_block(rt);   // constexpr on purpose: as a plain call the tree walk ran at run time
+      constexpr bool small = minv_small_grp(rt);
+      const long long nb = (small && skip_small != 0) ? 0 : (B + cpb - 1) / cpb;
       if (!done) {
         if (blk < nb) {
-          minv_cols_group<T, rt>(ws, B, dense, Minv, u_in, c_in, qdd_out, blk, smem_raw);
+          if constexpr (mcl_limbs(rt) > 0) {
+            minv_cols_limbs<T, rt>(ws, B, dense, Minv, u_in, c_in, qdd_out, blk, smem_raw);
+          } else {
+            minv_cols_group<T, rt>(ws, B, dense, Minv, u_in, c_in, qdd_out, blk, smem_raw);
+          }
           done = true;
         } else {
           blk -= nb;
@@ -1890,22 +2184,27 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   hipStream_t s = (hipStream_t)stream;
   T* ws = reinterpret_cast<T*>(workspace);
   const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
-  const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B);
-  if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
-  // otherwise eight lanes per configuration (rbd_minv_ia8.h)
-  if (pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4)) {
+  // otherwise eight lanes per configuration (rbd_minv_ia8.h), which also finishes the groups of <= 8 bodies
+  const bool lane_a = pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4);
+  const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B, !lane_a);
+  if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
+  if (lane_a) {
     hipLaunchKernelGGL(minv_ia_kernel<T>, dim3((unsigned)blocksA), dim3(64), 0, s, q, (long long)B, ws);
   } else {
-    hipLaunchKernelGGL(minv_ia8_kernel<T>, dim3((unsigned)((B + 7) / 8), n_groups()), dim3(64), 0, s, q, (long long)B, ws);
+    hipLaunchKernelGGL(minv_ia8_kernel<T>, dim3((unsigned)((B + 7) / 8), n_groups()), dim3(64), 0, s, q, (long long)B, ws, 1,
+                       output_dense, Minv, u, cbias, qdd);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase A launch");
-  constexpr size_t lds = minv_cols_lds_bytes<T>();
-  auto k = minv_cols_kernel<T>;
-  int rc;
-  if ((rc = ensure_lds(k, lds)) != 0) return rc;
-  hipLaunchKernelGGL(k, dim3((unsigned)blocksB), dim3(64), lds, s, (const T*)ws, (long long)B, output_dense, Minv, u, cbias, qdd);
+  if (blocksB > 0) {
+    constexpr size_t lds = minv_cols_lds_bytes<T>();
+    auto k = minv_cols_kernel<T>;
+    int rc;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocksB), dim3(64 * MINV_COLS_W), lds, s, (const T*)ws, (long long)B, output_dense, Minv, u, cbias,
+                       qdd, lane_a ? 0 : 1);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_minv phase B launch");
   return 0;

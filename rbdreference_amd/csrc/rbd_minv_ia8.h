@@ -8,8 +8,8 @@
 //   A[:, c]           = X^T Ia[:, c]            -> one xform_T per lane
 //   (X^T Ia X)[:, c]  = X^T (A[c, :])^T         -> row c of A is gathered through a 6 x 6 LDS transpose,
 //                                                  then one more xform_T per lane
-// i.e. 2 transforms per lane per body instead of 12 in one lane, and 8x the waves.  sin/cos of the
-// joints are computed once per group (lane c takes joints c, c + 8, ...) and broadcast the same way.
+// i.e. 2 transforms per lane per body instead of 12 in one lane, and 8x the waves.  sin/cos of the block's
+// joints are computed once per 8-lane group (lane c takes the c-th, (c + 8)-th ... joint) and broadcast the same way.
 // Writes the same [body][config][12] records as minv_ia_kernel.
 #pragma once
 #include "rbd_spatial.h"
@@ -39,10 +39,24 @@ constexpr int last_child_of(int p) {   // the child of p with the largest index 
   return m;
 }
 
+// Root subtrees of at most 8 bodies (Atlas' legs) are FINISHED here when `fuse_small` is set: the 8 lanes of a
+// configuration hold U, 1/D, sin, cos of every body anyway, and the articulated-inertia recursion visits the bodies
+// in the order of the columns' backward sweep, so lane c (< rows) carries column row0 + c along: its backward step
+// right after U_i, D_i exist, its forward sweep from the records kept in registers, its column into an LDS tile,
+// the group's rows out from there (and qdd = Minv (u - c) for forward dynamics).  No workspace round trip, and no
+// blocks of the column kernel: at B = 16 384 the legs' blocks there (12 body steps each) had cost as much as the
+// torso's (LDS capacity serialised the two: 12.8 of the column kernel's 25.5 us).
+constexpr bool minv_small_group(int rt) { return GRAD_PER_ROOT && grp_rows(rt) <= 8; }
+constexpr int IA8_TS = 8 * 8 + 1;              // LDS tile stride of a small group's [rows][rows] block
+
 template <class T>
-__global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q, long long B, T* __restrict__ ws) {
+__global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q, long long B, T* __restrict__ ws, int fuse_small,
+                                                         int dense, T* __restrict__ Minv, const T* __restrict__ u_in,
+                                                         const T* __restrict__ c_in, T* __restrict__ qdd_out) {
   __shared__ T tr_lds[64 * 6];                 // per-lane 6-vector exchange (one group = 8 x 6 values)
   __shared__ T im_lds[N * 36];                 // the robot's spatial inertias
+  __shared__ T tile_s[8 * IA8_TS];             // small groups: [configuration][rows][rows] of Minv
+  __shared__ T tau_s[8 * 8];                   //               u - c of the group's joints
   const int lane = threadIdx.x;
   const int c = lane & 7;                      // column owned by this lane (6, 7: idle columns)
   const int cc = c < 6 ? c : 0;                // clamp for table reads
@@ -51,26 +65,10 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
   const bool valid = b0 < B;
   const long long b = valid ? b0 : B - 1;
 
-  // sin / cos (or q for prismatic joints): lane c handles joints c, c + 8, c + 16, ...
-  constexpr int NR = (N + 7) / 8;
-  T s_l[NR], c_l[NR];
-  sfor<0, NR>([&](auto K) {
-    constexpr int k = decltype(K)::value;
-    const int j = k * 8 + c;
-    const int jj = j < N ? j : N - 1;
-    const T qv = q[b * N + jj];
-    T sv, cv;
-    sincos_(qv, &sv, &cv);
-    const bool pris = JTYPE[jj] != 0;           // runtime-indexed constexpr table
-    s_l[k] = sel(pris, qv, sv);
-    c_l[k] = sel(pris, T(0), cv);
-  });
   // Column cc of a body's spatial inertia (runtime column index) is read from an LDS copy of the
   // constant table when the body is first needed.  (Read lazily from the constant segment itself, each
   // body paid one L2 round trip on its critical path and the kernel was no faster than one lane per
   // configuration; read up front, the 6 N values spilled.)
-  for (int k = lane; k < N * 36; k += 64) im_lds[k] = T(IM[k / 36][k % 36]);
-  __syncthreads();
   // independent root subtrees (groups) run in separate blocks: blockIdx.y picks the group, which
   // shortens the serial body chain of a wave from n to the group's size
   const int gsel = blockIdx.y;
@@ -79,14 +77,39 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
    if constexpr (grp_head(rt)) {
    constexpr int gi = grp_index(rt);   // constexpr on purpose (a plain call would walk the tree at run time)
    if (gi == gsel) {
+  // sin / cos (or q for prismatic joints) of THIS group's joints only (the group's bodies are contiguous):
+  // lane c handles joints row0 + c, row0 + c + 8, ...  (all 30 joints in every wave had been a third of the
+  // kernel's VALU work)
+  constexpr int R0 = grp_row0(rt), RN = grp_rows(rt), NR = (RN + 7) / 8;
+  T s_l[NR], c_l[NR];
+  sfor<0, NR>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    const int j = R0 + k * 8 + c;
+    const int jj = j < R0 + RN ? j : R0 + RN - 1;
+    const T qv = q[b * N + jj];
+    T sv, cv;
+    sincos_(qv, &sv, &cv);
+    const bool pris = JTYPE[jj] != 0;           // runtime-indexed constexpr table
+    s_l[k] = sel(pris, qv, sv);
+    c_l[k] = sel(pris, T(0), cv);
+  });
+  for (int k = lane; k < RN * 36; k += 64) im_lds[R0 * 36 + k] = T(IM[R0 + k / 36][k % 36]);   // this group's inertias
+  __syncthreads();                            // (blockIdx.y is uniform: every thread of the block is in this branch)
   T IAc[N][6];
+  constexpr bool SMALL = minv_small_group(rt);
+  const bool fused = SMALL && fuse_small != 0;
+  // this lane's column of a small group (lanes c >= rows repeat the last one and store nothing)
+  const int jc = R0 + (c < RN ? c : RN - 1);
+  T Us[N][6], Ds[N], mcol[N];
+  JTrig<T> trs[N];
+  T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   sfor_down<grp_row0(rt), grp_row0(rt) + grp_rows(rt)>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int p = PARENT[i];
     constexpr int si = s_index(i);
     JTrig<T> tri;
-    tri.s = grp8_bcast<i % 8>(s_l[i / 8]);
-    tri.c = grp8_bcast<i % 8>(c_l[i / 8]);
+    tri.s = grp8_bcast<(i - R0) % 8>(s_l[(i - R0) / 8]);
+    tri.c = grp8_bcast<(i - R0) % 8>(c_l[(i - R0) / 8]);
     if constexpr (!has_child(i)) {
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[i][r] = im_lds[i * 36 + r * 6 + cc]; });
     }
@@ -107,7 +130,25 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
         sfor<1, VPB>([&](auto P) { constexpr int pp = decltype(P)::value; x = sel(c == pp, flat[pp * VE + e], x); });
         piece[e] = x;
       });
-      if (valid && c < VPB) reinterpret_cast<V*>(ws + ((long long)i * B + b) * MINV_WS)[c] = piece;
+      if (valid && c < VPB && !fused) reinterpret_cast<V*>(ws + ((long long)i * B + b) * MINV_WS)[c] = piece;
+    }
+    if constexpr (SMALL) {
+      if (fused) {
+        // backward step of column jc at body i (:700-726), as in minv_cols_group
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Us[i][r] = U[r]; });
+        Ds[i] = Dinv; trs[i] = tri;
+        constexpr unsigned long long mask = subtree_mask(i);
+        const bool insub = ((mask >> jc) & 1ull) != 0;
+        T m = sel(jc == i, Dinv, -(Dinv * S_dot<i>(Fj)));
+        m = sel(insub, m, T(0));
+        mcol[i] = m;
+        if constexpr (p >= 0) {
+          T t[6], y[6];
+          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(U[r], m, Fj[r]); });
+          xform_T<i>(tri, t, y);
+          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fj[r] = sel(insub, y[r], Fj[r]); });
+        }
+      }
     }
     if constexpr (p >= 0) {
       // Ia[:, c] = IA[:, c] - U * (U[c] / D), with U[c] = IA[s][c] = this lane's element s
@@ -136,6 +177,81 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
       pin6(IAc[p]);   // ordering point: keeps the bodies in program order (bounds live registers)
     }
   });
+  if constexpr (SMALL) {
+    if (fused) {
+      // ---- forward sweep of column jc (:760-781) from the records kept in registers -------------------------------
+      T Ff[N][6];
+      sfor<R0, R0 + RN>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int p = PARENT[i];
+        constexpr int si = s_index(i);
+        if constexpr (p < 0) {
+          sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
+          Ff[i][si] = mcol[i];
+        } else {
+          xform<i>(trs[i], Ff[p], Ff[i]);
+          const T m = fma_(-Ds[i], dot6(Us[i], Ff[i]), mcol[i]);
+          mcol[i] = m;
+          Ff[i][si] += m;
+        }
+      });
+      // ---- the column into the tile, mirrored (:799-804) -----------------------------------------------------------
+      T* myt = tile_s + grp * IA8_TS;                    // myt[(i - R0) * RN + (col - R0)]
+      const int jl = jc - R0;
+      if (c < RN) {
+        sfor<R0, R0 + RN>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          if (i <= jc) myt[(i - R0) * RN + jl] = mcol[i];
+          if (i < jc) myt[jl * RN + (i - R0)] = sel(dense != 0, mcol[i], T(0));
+        });
+      }
+      __syncthreads();
+      const long long cfg0 = (long long)blockIdx.x * 8;
+      const long long rem = B - cfg0;
+      const int nvalid = rem < 8 ? (int)rem : 8;
+      if (qdd_out != nullptr) {                          // forward dynamics (:1371-1374): lane jc owns row jc
+        if (valid && c < RN) tau_s[grp * 8 + jl] = u_in[b * N + jc] - c_in[b * N + jc];
+        __syncthreads();
+        if (valid && c < RN) {
+          T o = T(0);
+          sfor<0, RN>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[jl * RN + k], tau_s[grp * 8 + k], o); });
+          qdd_out[b * N + jc] = o;
+        }
+      }
+      if (Minv != nullptr) {
+        constexpr int RW = RN * N;
+        T* gdst = Minv + cfg0 * (N * N) + R0 * N;
+        auto elem = [&](int cfg, int e) -> T {           // (row e / N, column e % N): own columns from the tile, the rest zero
+          const int r = e / N;
+          const int cidx = e - r * N - R0;
+          const bool own = cidx >= 0 && cidx < RN;
+          const T x = tile_s[cfg * IA8_TS + r * RN + (own ? cidx : 0)];
+          return own ? x : T(0);
+        };
+        if constexpr (minv_vec_flush(rt) && sizeof(T) == 4) {
+          typedef T V __attribute__((ext_vector_type(4)));
+          constexpr int RV = RW / 4;
+          const int total = nvalid * RV;
+#pragma unroll 2
+          for (int g = lane; g < total; g += 64) {
+            const int cfg = g / RV;
+            const int r4 = g - cfg * RV;
+            V x;
+            x[0] = elem(cfg, 4 * r4); x[1] = elem(cfg, 4 * r4 + 1); x[2] = elem(cfg, 4 * r4 + 2); x[3] = elem(cfg, 4 * r4 + 3);
+            reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
+          }
+        } else {
+          const int total = nvalid * RW;
+#pragma unroll 4
+          for (int g = lane; g < total; g += 64) {
+            const int cfg = g / RW;
+            const int r2 = g - cfg * RW;
+            gdst[(long long)cfg * (N * N) + r2] = elem(cfg, r2);
+          }
+        }
+      }
+    }
+  }
    }
    }
   });
