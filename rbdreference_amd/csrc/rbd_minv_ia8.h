@@ -3,7 +3,7 @@
 // configuration (Atlas, B = 16 384: 256 waves on 1 024 SIMDs).
 //
 // Lane c (< 6) of a configuration's 8-lane group owns COLUMN c of every articulated inertia IA_i:
-//   U = IA S          = column s of IA          -> broadcast from lane s with ds_swizzle (no LDS memory)
+//   U = IA S          = column s of IA          -> broadcast from lane s with two DPP moves (no LDS)
 //   Ia[:, c]          = IA[:, c] - U (U[c] / D) -> U[c] is the lane's own element s (IA is symmetric)
 //   A[:, c]           = X^T Ia[:, c]            -> one xform_T per lane
 //   (X^T Ia X)[:, c]  = X^T (A[c, :])^T         -> row c of A is gathered through a 6 x 6 LDS transpose,
@@ -16,19 +16,26 @@
 
 namespace rbdk {
 
-// broadcast the value of lane L (0..7) of every aligned 8-lane group: ds_swizzle bit-mode,
-// lane' = (lane & 0x18) | L  within each 32-lane half
+// broadcast the value of lane L (0..7) of every aligned 8-lane group with two DPP moves (VALU, no LDS
+// traffic): quad_perm spreads lane L % 4 of every quad over its quad, then row_half_mirror (lane i <- lane 7 - i
+// of its 8-lane half row) carries the value of L's quad into the other quad of the group -- bank_mask
+// enables only the quads that do not hold L, the others keep the first move's result.  (The first version
+// used ds_swizzle: 8 LDS-pipe operations per body, and at B = 16 384 the kernel's body steps were bound by
+// the CU's LDS issue rate, 0.5 us per body against 0.2 us for a lone block.)
 template <int L>
-RBD_DEV float grp8_bcast(float x) {
-  constexpr int pattern = (0x18) | (L << 5) | (0 << 10);   // and_mask[4:0] | or_mask[9:5] | xor_mask[14:10]
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), pattern));
+RBD_DEV int grp8_bcast_i(int x) {
+  constexpr int q = L % 4;
+  constexpr int quad = q | (q << 2) | (q << 4) | (q << 6);          // quad_perm [q, q, q, q]
+  const int x1 = __builtin_amdgcn_update_dpp(x, x, quad, 0xF, 0xF, false);
+  return __builtin_amdgcn_update_dpp(x1, x1, 0x141 /* row_half_mirror */, 0xF, L < 4 ? 0xA : 0x5, false);
 }
 template <int L>
+RBD_DEV float grp8_bcast(float x) { return __builtin_bit_cast(float, grp8_bcast_i<L>(__builtin_bit_cast(int, x))); }
+template <int L>
 RBD_DEV double grp8_bcast(double x) {
-  constexpr int pattern = (0x18) | (L << 5);
   unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  int lo = __builtin_amdgcn_ds_swizzle((int)(u & 0xffffffffu), pattern);
-  int hi = __builtin_amdgcn_ds_swizzle((int)(u >> 32), pattern);
+  int lo = grp8_bcast_i<L>((int)(u & 0xffffffffu));
+  int hi = grp8_bcast_i<L>((int)(u >> 32));
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
