@@ -630,12 +630,15 @@ __global__ __launch_bounds__(64 * RG_WAVES) void rnea_groups_kernel(const T* __r
 // arms under the third back joint) are independent of each other between the moment their parent's v, a
 // exist and the moment their root force goes back to it (:576-581, :618-619), so each limb gets its own
 // wave of the block and the group's remaining bodies ("stem") another:
-//   phase 1   stems and limb-less groups: forward
-//   phase 2   limbs: forward (parent's v, a from the shared LDS image)  |  limb-less groups: backward
-//   phase 3   limbs: backward, X^T f of the limb's root parked for the parent  |  other waves stream v out
-//   phase 4   stems: parked limb forces added, backward                  |  other waves stream a out
+//   phase 1   stems: forward of the SPINE (the bodies above a limb)     |  limb-less groups: their first steps
+//   phase 2   limbs: forward (parent's v, a from the shared LDS image)  |  stems: the rest (Atlas' neck), forward
+//             and backward  |  limb-less groups: the rest of forward, then backward steps
+//   phase 3   limbs: backward, X^T f of the limb's root parked for the parent  |  other waves: leftover backward
+//             steps, then stream v out
+//   phase 4   stems: parked limb forces added, backward of the spine    |  other waves stream a out
 //   phase 5   every wave: f and c out
-// Atlas: 6 + 7 + 7 + 4 = 24 serial body steps instead of 36, and two thirds of the output leave while the
+// Every wave loads its inputs and computes its sin / cos before the first barrier.
+// Atlas: 3 + 7 + 7 + 3 = 20 serial body steps instead of 36, and two thirds of the output leave while the
 // backward passes run: at B = 16 384 (one block per CU, so no other block to overlap with) the launch was
 // 6 us of recursion followed by 6 us of stores at HBM speed.  v, a, f have an LDS image each.
 // ---------------------------------------------------------------------------------------------
@@ -656,6 +659,46 @@ constexpr int n_busy_stems() {             // stems that wait for limbs: the wav
   int k = 0;
   for (int x = 0; x < N; ++x) k += (PARENT[x] == -1 && stem_has_limbs(x)) ? 1 : 0;
   return k;
+}
+// the stem's spine: the stem bodies above a limb (everything the limbs wait for)
+constexpr bool rs_spine(int j) {
+  if (limb_of(j) != -1) return false;
+  for (int x = 0; x < N; ++x)
+    if (limb_head(x) && is_anc_or_self(j, PARENT[x])) return true;
+  return false;
+}
+constexpr int rs_budget1() {                // longest spine: the length of phase 1
+  int m = 0;
+  for (int r = 0; r < N; ++r)
+    if (PARENT[r] == -1) {
+      int k = 0;
+      for (int j = 0; j < N; ++j) k += (root_of(j) == r && rs_spine(j)) ? 1 : 0;
+      m = k > m ? k : m;
+    }
+  return m;
+}
+constexpr int rs_budget2() {                // longest limb: the length of phase 2
+  int m = 0;
+  for (int h = 0; h < N; ++h)
+    if (limb_head(h)) {
+      int k = 0;
+      for (int j = 0; j < N; ++j) k += limb_of(j) == h ? 1 : 0;
+      m = k > m ? k : m;
+    }
+  return m;
+}
+constexpr int rs_rows(int h) {              // bodies of segment h
+  int k = 0;
+  for (int j = 0; j < N; ++j) k += seg_has(h, j) ? 1 : 0;
+  return k;
+}
+constexpr int rs_body(int h, int k) {       // k-th body of segment h
+  for (int j = 0; j < N; ++j)
+    if (seg_has(h, j)) {
+      if (k == 0) return j;
+      --k;
+    }
+  return -1;
 }
 constexpr int RS_PARK = 7;                  // 6 scalars per (limb, configuration), odd stride
 template <class T>
@@ -689,12 +732,14 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rnea_segments_kernel(const T* _
   T* myC = tileC + lane * KPN;
 
   JTrig<T> tr[N];
-  T f[N][6];
+  T qdv[N], qddv[N];
+  T v[N][6], a[N][6], f[N][6];
   const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-  // forward pass over the bodies of segment H (:569-596); a limb takes its parent's v, a from the images
-  auto forward = [&](auto H) {
+  // inputs and sin / cos of segment H's joints: done by every wave before the first barrier (the limbs' waves
+  // have nothing else to do in phase 1)
+  auto load_inputs = [&](auto H) {
     constexpr int h = decltype(H)::value;
-    T qv[N], qdv[N], qddv[N];
+    T qv[N];
     sfor<0, N>([&](auto J) {
       constexpr int j = decltype(J)::value;
       if constexpr (seg_has(h, j)) {
@@ -704,58 +749,57 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rnea_segments_kernel(const T* _
       }
     });
     sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j)) tr[j] = make_trig<j>(qv[j]); });
-    T v[N][6], a[N][6];
-    sfor<0, N>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      constexpr int p = PARENT[j];
-      if constexpr (seg_has(h, j)) {
-        T xv[6], xa[6];
-        if constexpr (p < 0) {
-          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
-        } else if constexpr (!seg_has(h, p)) {          // the limb's root: its parent lives in the stem's wave
-          T vp[6], ap[6];
-          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; vp[r] = myV[r * N + p]; ap[r] = myA[r * N + p]; });
-          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, vp, ap, xv, xa, v[j], a[j], f[j]);
-        } else {
-          rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
-        }
-        sfor<0, 6>([&](auto R) {       // reference layout (6, NB): element [r][j]
-          constexpr int r = decltype(R)::value;
-          myV[r * N + j] = v[j][r];
-          myA[r * N + j] = a[j][r];
-        });
-        pin6(f[j]);                    // keep the bodies in program order (bounds the live v / a set)
-      }
-    });
   };
-  // backward pass over the bodies of segment H (:607-619)
-  auto backward = [&](auto H) {
-    constexpr int h = decltype(H)::value;
-    sfor_down<0, N>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      constexpr int p = PARENT[j];
-      if constexpr (seg_has(h, j)) {
-        myC[j] = S_dot<j>(f[j]);
-        if constexpr (p >= 0) {
-          T t[6];
-          xform_T<j>(tr[j], f[j], t);
-          if constexpr (seg_has(h, p)) {
-            sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
-          } else {                                        // limb root -> parked for the stem
-            constexpr int li = limb_index(h);           // (bound to a constant: a constexpr call in a run-time expression is not folded)
-            T* pk = park + (li * 64 + lane) * RS_PARK;
-            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; pk[r] = t[r]; });
-          }
-        }
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; myF[r * N + j] = f[j][r]; });
-      }
+  // forward step of body J of segment H (:569-596); a limb's root takes its parent's v, a from the images
+  auto fwd_body = [&](auto H, auto J) {
+    constexpr int h = decltype(H)::value, j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    T xv[6], xa[6];
+    if constexpr (p < 0) {
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, zero6, zero6, xv, xa, v[j], a[j], f[j]);
+    } else if constexpr (!seg_has(h, p)) {          // the limb's root: its parent lives in the stem's wave
+      T vp[6], ap[6];
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; vp[r] = myV[r * N + p]; ap[r] = myA[r * N + p]; });
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, vp, ap, xv, xa, v[j], a[j], f[j]);
+    } else {
+      rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
+    }
+    sfor<0, 6>([&](auto R) {       // reference layout (6, NB): element [r][j]
+      constexpr int r = decltype(R)::value;
+      myV[r * N + j] = v[j][r];
+      myA[r * N + j] = a[j][r];
     });
+    pin6(f[j]);                    // keep the bodies in program order (bounds the live v / a set)
+  };
+  // backward step of body J of segment H (:607-619)
+  auto bwd_body = [&](auto H, auto J) {
+    constexpr int h = decltype(H)::value, j = decltype(J)::value;
+    constexpr int p = PARENT[j];
+    myC[j] = S_dot<j>(f[j]);
+    if constexpr (p >= 0) {
+      T t[6];
+      xform_T<j>(tr[j], f[j], t);
+      if constexpr (seg_has(h, p)) {
+        sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+      } else {                                        // limb root -> parked for the stem
+        constexpr int li = limb_index(h);           // (bound to a constant: a constexpr call in a run-time expression is not folded)
+        T* pk = park + (li * 64 + lane) * RS_PARK;
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; pk[r] = t[r]; });
+      }
+    }
+    sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; myF[r * N + j] = f[j][r]; });
   };
   // Every wave walks its own segment's timeline (same number of barriers on every path): kept as ONE branch
   // per wave so that a segment's registers (its f and sin / cos across the phases) are not live through the
   // code of the other segments -- phase-by-phase dispatch had put the whole block's state into one wave's
   // register file (256 VGPRs and spills instead of 111).
+  //   stem   1: forward of its SPINE (the bodies above a limb)   2: the other stem bodies, forward and backward
+  //          3: streams v   4: parked limb forces, backward of the spine
+  //   limb   1: --   2: forward   3: backward, root force parked   4: streams a
+  //   other  its 2 x rows steps (forward, then backward) spread over phases 1-3 with the stem's / limbs' step
+  //          counts as budgets (all forward steps by the end of phase 2), then streams v;  4: streams a
   constexpr int NT3 = 64 * (RS_WAVES - n_limbs()), NT4 = 64 * (RS_WAVES - n_busy_stems());
+  constexpr int B1 = rs_budget1(), B2 = rs_budget2();
   sfor<0, N>([&](auto H) {
     constexpr int h = decltype(H)::value;
     if constexpr (seg_head(h)) {
@@ -764,15 +808,22 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rnea_segments_kernel(const T* _
       constexpr bool stem = !limb && stem_has_limbs(h);
       constexpr int rank3 = seg_rank<false>(h), rank4 = seg_rank<true>(h);   // among the waves that stream in phase 3 / 4
       if (wave == si) {
-        if constexpr (!limb) forward(H);                                          // phase 1
-        __syncthreads();
-        if constexpr (limb) forward(H);                                           // phase 2
-        else if constexpr (!stem) backward(H);
-        __syncthreads();
-        if constexpr (limb) backward(H);                                          // phase 3
-        else flush_tile_nt<K6, NT3>(tileV, v_out + cfg0 * K6, rank3 * 64 + lane, nvalid);
-        __syncthreads();
-        if constexpr (stem) {                                                     // phase 4
+        load_inputs(H);
+        if constexpr (limb) {
+          __syncthreads();
+          sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j)) fwd_body(H, J); });
+          __syncthreads();
+          sfor_down<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j)) bwd_body(H, J); });
+          __syncthreads();
+          flush_tile_nt<K6, NT4>(tileA, a_out + cfg0 * K6, rank4 * 64 + lane, nvalid);
+        } else if constexpr (stem) {
+          sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j) && rs_spine(j)) fwd_body(H, J); });
+          __syncthreads();
+          sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j) && !rs_spine(j)) fwd_body(H, J); });
+          sfor_down<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j) && !rs_spine(j)) bwd_body(H, J); });
+          __syncthreads();
+          flush_tile_nt<K6, NT3>(tileV, v_out + cfg0 * K6, rank3 * 64 + lane, nvalid);
+          __syncthreads();
           sfor_down<0, N>([&](auto L) {       // descending, the order in which the reference's loop adds them (:618)
             constexpr int l = decltype(L)::value;
             if constexpr (limb_head(l) && root_of(l) == h) {
@@ -781,8 +832,28 @@ __global__ __launch_bounds__(64 * RS_WAVES) void rnea_segments_kernel(const T* _
               sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; f[pl][r] += pk[r]; });
             }
           });
-          backward(H);
+          sfor_down<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (seg_has(h, j) && rs_spine(j)) bwd_body(H, J); });
         } else {
+          // a limb-less root subtree: step k < rows is the forward step of its k-th body, step rows + k the backward
+          // step of its (rows - 1 - k)-th body
+          constexpr int rows = rs_rows(h);
+          constexpr int e1 = B1 < rows ? B1 : rows;                                  // steps [0, e1) in phase 1
+          constexpr int e2 = (e1 + B2 > rows ? e1 + B2 : rows) < 2 * rows ? (e1 + B2 > rows ? e1 + B2 : rows) : 2 * rows;   // [e1, e2) in phase 2
+          auto steps = [&](auto A, auto E) {
+            constexpr int a0 = decltype(A)::value, e0 = decltype(E)::value;
+            sfor<a0, e0>([&](auto K) {
+              constexpr int k = decltype(K)::value;
+              if constexpr (k < rows) fwd_body(H, std::integral_constant<int, rs_body(h, k)>{});
+              else bwd_body(H, std::integral_constant<int, rs_body(h, 2 * rows - 1 - k)>{});
+            });
+          };
+          steps(std::integral_constant<int, 0>{}, std::integral_constant<int, e1>{});
+          __syncthreads();
+          steps(std::integral_constant<int, e1>{}, std::integral_constant<int, e2>{});
+          __syncthreads();
+          steps(std::integral_constant<int, e2>{}, std::integral_constant<int, 2 * rows>{});
+          flush_tile_nt<K6, NT3>(tileV, v_out + cfg0 * K6, rank3 * 64 + lane, nvalid);
+          __syncthreads();
           flush_tile_nt<K6, NT4>(tileA, a_out + cfg0 * K6, rank4 * 64 + lane, nvalid);
         }
       }
