@@ -69,8 +69,10 @@ int rbd_model_info(rbd_model_info_t* out);
  *   RBD_OPT_GRAD_KERNEL    rbd_rnea_grad: AUTO | TREE (chain-by-chain world-frame kernel) | COLS (one
  *                          lane per derivative column: AUTO picks it for small batches) | BATCH (the
  *                          robot's batch-parallel kernel at every batch size)
- *   RBD_OPT_MINV_PHASE_A   rbd_minv, two-phase robots: AUTO | LANE (one lane per configuration) |
- *                          IA8 (eight lanes per configuration)
+ *   RBD_OPT_MINV_PHASE_A   rbd_minv, robots too big for the one-lane kernel: AUTO | LANE (phase A with one lane
+ *                          per configuration, then the column kernel) | IA8 (eight lanes per configuration,
+ *                          then the column kernel) | FUSED (one launch from q to Minv; robots whose big
+ *                          root subtrees have limbs; what AUTO picks for them)
  *   RBD_OPT_RNEA_KERNEL    rbd_rnea with v, a, f: AUTO | BATCH (one lane per configuration) | GROUPS (one
  *                          wave per independent root subtree).  AUTO: robots whose root subtrees carry
  *                          several big branches (Atlas' arms) get one wave per branch / stem / root
@@ -91,6 +93,7 @@ int rbd_model_info(rbd_model_info_t* out);
 #define RBD_MINV_PHASE_A_AUTO 0
 #define RBD_MINV_PHASE_A_LANE 1
 #define RBD_MINV_PHASE_A_IA8 2
+#define RBD_MINV_PHASE_A_FUSED 3
 #define RBD_OP_RNEA 0
 #define RBD_OP_RNEA_GRAD 1
 #define RBD_OP_MINV 2

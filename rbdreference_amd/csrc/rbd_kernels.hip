@@ -19,7 +19,8 @@
 //   minv        minv_lane_kernel (rbd_minv_lane.h): one lane per configuration, fused, for robots with
 //               small root groups; otherwise phase A (minv_ia_kernel / minv_ia8_kernel) + phase B
 //               (minv_cols_kernel, one lane per COLUMN, one wave per column class of a group with limbs)
-//               through a [body][config][12] workspace; minv_ia8_kernel also finishes the groups of <= 8 bodies.
+//               through a [body][config][12] workspace; minv_ia8_kernel also finishes the groups of <= 8 bodies;
+//               robots whose big groups have limbs (Atlas): minv_fused_kernel (rbd_minv_fused.h), one launch.
 //   crba, rnea_fpass / rnea_bpass, forward_dynamics(_grad): further rows, same building blocks.
 // The library is built from several translation units of this one file (rbdreference_amd/build.py
 // compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
@@ -1355,6 +1356,16 @@ constexpr int mcl_col(int rt, int cls, int k) {      // k-th column of the class
     }
   return -1;
 }
+constexpr int mcl_index(int rt, int cls, int i) {    // position of column / body i within the class
+  int k = 0;
+  for (int j = 0; j < i; ++j) k += mcl_has(rt, cls, j) ? 1 : 0;
+  return k;
+}
+constexpr int limb_rank_in_group(int h) {            // ordinal of limb h among the limbs of its root subtree
+  int k = 0;
+  for (int x = 0; x < h; ++x) k += (limb_head(x) && root_of(x) == root_of(h)) ? 1 : 0;
+  return k;
+}
 constexpr int mcl_max(int rt, int cls) {
   int m = -1;
   for (int j = 0; j < N; ++j)
@@ -1581,10 +1592,11 @@ constexpr int mcl_first_fwd(int rt, int cls) { return mcl_next_fwd(rt, cls, -1);
 // The two sweeps of ONE column class of a group with limbs (wave CLS of the block): same arithmetic as
 // minv_cols_group, restricted at compile time to the bodies the class needs; fills the class' columns of
 // the shared tile (and their mirror images).
-template <class T, int RT, int CLS>
+template <class T, int RT, int CLS, int CPB = mcl_cpb(RT)>
 RBD_DEV void minv_cols_class(const T* wsl, T* tile, int dense, int lane, int& slot_out, int& j_out, bool& spare_out) {
   constexpr int row0 = grp_row0(RT), rows = grp_rows(RT);
-  constexpr int LC = mcl_count(RT, CLS), CPB = mcl_cpb(RT), TS = minv_tso(RT);
+  constexpr int LC = mcl_count(RT, CLS), TS = minv_tso(RT);
+  static_assert(CPB * LC <= 64, "a class' columns of the block's configurations must fit one wave");
   const int slot0 = lane / LC;
   const bool spare = slot0 >= CPB;       // lanes beyond CPB * LC
   const int slot = spare ? CPB - 1 : slot0;
@@ -1829,6 +1841,7 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
 #include "rbd_minv_lane.h"     // also defines MINV_LANE_OK, which sizes the workspaces (every unit)
 #ifdef RBD_NEED_MINV
 #include "rbd_minv_ia8.h"
+#include "rbd_minv_fused.h"
 #endif
 #if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64)
 #include "rbd_crba.h"
@@ -2257,6 +2270,22 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
   // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
   // otherwise eight lanes per configuration (rbd_minv_ia8.h), which also finishes the groups of <= 8 bodies
+  // a robot whose big groups have limbs: everything in one launch (rbd_minv_fused.h); measured on Atlas against the
+  // two launches: 11.5 vs 17.3 us at B = 4 096, 27.0 vs 33.8 at 16 384, 174 vs 233 at 131 072, 785 vs 928 at 524 288
+  if constexpr (MINV_FUSED_OK && mf_lds_bytes<T>() <= 160 * 1024) {
+    if (pa == RBD_MINV_PHASE_A_FUSED || pa == RBD_MINV_PHASE_A_AUTO) {
+      const int64_t nbf = mf_blocks(B);
+      if (nbf > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
+      constexpr size_t ldsf = mf_lds_bytes<T>();
+      auto kf = minv_fused_kernel<T>;
+      int rcf;
+      if ((rcf = ensure_lds(kf, ldsf)) != 0) return rcf;
+      hipLaunchKernelGGL(kf, dim3((unsigned)nbf), dim3(64 * MF_W), ldsf, s, q, (long long)B, output_dense, Minv, u, cbias, qdd);
+      hipError_t ef = hipGetLastError();
+      if (ef != hipSuccess) return hip_fail(ef, "rbd_minv (fused) launch");
+      return 0;
+    }
+  }
   const bool lane_a = pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4);
   const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B, !lane_a);
   if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
@@ -2285,9 +2314,15 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
 // name of the dominant kernel minv_launch<T> would run for B rows under the current options
 template <class T>
 int minv_kernel_name(int64_t B, char* buf, size_t len) {
-  (void)B;
   const char* t = sizeof(T) == 4 ? "float" : "double";
+  const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
+  bool fused = false;
+  if constexpr (!rbdk::MINV_USE_LANE) {
+    if constexpr (rbdk::MINV_FUSED_OK && rbdk::mf_lds_bytes<T>() <= 160 * 1024)
+      fused = pa == RBD_MINV_PHASE_A_FUSED || pa == RBD_MINV_PHASE_A_AUTO;
+  }
   if (rbdk::MINV_USE_LANE) std::snprintf(buf, len, "minv_lane_kernel<%s>", t);
+  else if (fused) std::snprintf(buf, len, "minv_fused_kernel<%s>", t);
   else std::snprintf(buf, len, "minv_cols_kernel<%s>", t);
   return 0;
 }
@@ -2504,7 +2539,7 @@ const char* rbd_last_error(void) { return rbd_err_buf(); }
 int rbd_set_option(int option, int value) {
   std::atomic<int>* s = rbd_option_slot(option);
   if (!s) return fail(RBD_ERR_ARG, "rbd_set_option: unknown option");
-  if (value < 0 || value > (option == RBD_OPT_GRAD_KERNEL ? RBD_GRAD_KERNEL_BATCH : 2))
+  if (value < 0 || value > (option == RBD_OPT_RNEA_KERNEL ? 2 : 3))
     return fail(RBD_ERR_ARG, "rbd_set_option: value out of range");
   s->store(value, std::memory_order_relaxed);
   return 0;

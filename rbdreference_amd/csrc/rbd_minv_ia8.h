@@ -56,34 +56,19 @@ constexpr int last_child_of(int p) {   // the child of p with the largest index 
 constexpr bool minv_small_group(int rt) { return GRAD_PER_ROOT && grp_rows(rt) <= 8; }
 constexpr int IA8_TS = 8 * 8 + 1;              // LDS tile stride of a small group's [rows][rows] block
 
-template <class T>
-__global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q, long long B, T* __restrict__ ws, int fuse_small,
-                                                         int dense, T* __restrict__ Minv, const T* __restrict__ u_in,
-                                                         const T* __restrict__ c_in, T* __restrict__ qdd_out) {
-  __shared__ T tr_lds[64 * 6];                 // per-lane 6-vector exchange (one group = 8 x 6 values)
-  __shared__ T im_lds[N * 36];                 // the robot's spatial inertias
-  __shared__ T tile_s[8 * IA8_TS];             // small groups: [configuration][rows][rows] of Minv
-  __shared__ T tau_s[8 * 8];                   //               u - c of the group's joints
-  const int lane = threadIdx.x;
+// One group (root subtree) RT for the 8 configurations cfg0 .. cfg0 + 7, by ONE wave: `lane` = lane of that wave,
+// tr_lds [64 * 6], im_lds [N * 36], tile_s [8 * IA8_TS], tau_s [64] = LDS of that wave (im_lds may be shared by
+// waves that work on the same group).  Contains block barriers: every wave of the block must call it.
+template <class T, int rt>
+RBD_DEV void ia8_group(const T* __restrict__ q, long long B, T* __restrict__ ws, int fuse_small, int dense, T* __restrict__ Minv,
+                       const T* __restrict__ u_in, const T* __restrict__ c_in, T* __restrict__ qdd_out, long long cfg0, int lane,
+                       T* tr_lds, T* im_lds, T* tile_s, T* tau_s) {
   const int c = lane & 7;                      // column owned by this lane (6, 7: idle columns)
   const int cc = c < 6 ? c : 0;                // clamp for table reads
   const int grp = lane >> 3;
-  const long long b0 = (long long)blockIdx.x * 8 + grp;
+  const long long b0 = cfg0 + grp;
   const bool valid = b0 < B;
   const long long b = valid ? b0 : B - 1;
-
-  // Column cc of a body's spatial inertia (runtime column index) is read from an LDS copy of the
-  // constant table when the body is first needed.  (Read lazily from the constant segment itself, each
-  // body paid one L2 round trip on its critical path and the kernel was no faster than one lane per
-  // configuration; read up front, the 6 N values spilled.)
-  // independent root subtrees (groups) run in separate blocks: blockIdx.y picks the group, which
-  // shortens the serial body chain of a wave from n to the group's size
-  const int gsel = blockIdx.y;
-  sfor<0, N>([&](auto Rt_) {
-   constexpr int rt = decltype(Rt_)::value;
-   if constexpr (grp_head(rt)) {
-   constexpr int gi = grp_index(rt);   // constexpr on purpose (a plain call would walk the tree at run time)
-   if (gi == gsel) {
   // sin / cos (or q for prismatic joints) of THIS group's joints only (the group's bodies are contiguous):
   // lane c handles joints row0 + c, row0 + c + 8, ...  (all 30 joints in every wave had been a third of the
   // kernel's VALU work)
@@ -101,7 +86,7 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
     c_l[k] = sel(pris, T(0), cv);
   });
   for (int k = lane; k < RN * 36; k += 64) im_lds[R0 * 36 + k] = T(IM[R0 + k / 36][k % 36]);   // this group's inertias
-  __syncthreads();                            // (blockIdx.y is uniform: every thread of the block is in this branch)
+  __syncthreads();                            // (every wave of the block is in a call of this function)
   T IAc[N][6];
   constexpr bool SMALL = minv_small_group(rt);
   const bool fused = SMALL && fuse_small != 0;
@@ -213,9 +198,8 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
         });
       }
       __syncthreads();
-      const long long cfg0 = (long long)blockIdx.x * 8;
       const long long rem = B - cfg0;
-      const int nvalid = rem < 8 ? (int)rem : 8;
+      const int nvalid = rem < 8 ? (rem > 0 ? (int)rem : 0) : 8;
       if (qdd_out != nullptr) {                          // forward dynamics (:1371-1374): lane jc owns row jc
         if (valid && c < RN) tau_s[grp * 8 + jl] = u_in[b * N + jc] - c_in[b * N + jc];
         __syncthreads();
@@ -259,8 +243,27 @@ __global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q
       }
     }
   }
-   }
-   }
+}
+
+template <class T>
+__global__ __launch_bounds__(64, 2) void minv_ia8_kernel(const T* __restrict__ q, long long B, T* __restrict__ ws, int fuse_small,
+                                                         int dense, T* __restrict__ Minv, const T* __restrict__ u_in,
+                                                         const T* __restrict__ c_in, T* __restrict__ qdd_out) {
+  __shared__ T tr_lds[64 * 6];                 // per-lane 6-vector exchange (one group = 8 x 6 values)
+  __shared__ T im_lds[N * 36];                 // the robot's spatial inertias
+  __shared__ T tile_s[8 * IA8_TS];             // small groups: [configuration][rows][rows] of Minv
+  __shared__ T tau_s[8 * 8];                   //               u - c of the group's joints
+  // independent root subtrees (groups) run in separate blocks: blockIdx.y picks the group, which
+  // shortens the serial body chain of a wave from n to the group's size
+  const int gsel = blockIdx.y;
+  sfor<0, N>([&](auto Rt_) {
+    constexpr int rt = decltype(Rt_)::value;
+    if constexpr (grp_head(rt)) {
+      constexpr int gi = grp_index(rt);   // constexpr on purpose (a plain call would walk the tree at run time)
+      if (gi == gsel)
+        ia8_group<T, rt>(q, B, ws, fuse_small, dense, Minv, u_in, c_in, qdd_out, (long long)blockIdx.x * 8, (int)threadIdx.x,
+                         tr_lds, im_lds, tile_s, tau_s);
+    }
   });
 }
 

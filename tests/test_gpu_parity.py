@@ -606,14 +606,16 @@ def test_tree_gradient_kernel_forced_on_every_robot():
     assert ran_tree >= 8, ran_tree      # iiwa, quadruped, chain, tree in both precisions, Atlas in fp32, ...
 
 
-@pytest.mark.parametrize("name", ["atlas_like", "random_tree_n9", "random_forest_n8"])
+@pytest.mark.parametrize("name", ["atlas_like", "random_limbs_n14", "random_tree_n9", "random_forest_n8"])
 def test_minv_both_phase_a_kernels(name):
-    """Two-phase minv robots: phase A with one lane per configuration (the default from B = 262 144)
-    and with eight lanes per configuration (the default below) feed the same phase B; both are held
-    to the golden vectors and to each other on a ragged batch."""
+    """Robots too big for the one-lane minv kernel: phase A with one lane per configuration (the default from
+    B = 262 144) and with eight lanes per configuration feed the column kernel; robots whose big groups have
+    limbs (Atlas, the 14-body tree) also have the one-launch kernel (their default; a request
+    for it on another robot falls back to the two launches).  All are held to the golden vectors and to the oracle
+    on a ragged batch, forward dynamics included."""
     torch = _torch()
-    from rbdreference_amd._lib import (RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_IA8, RBD_MINV_PHASE_A_LANE,
-                                       RBD_OPT_MINV_PHASE_A)
+    from rbdreference_amd._lib import (RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_FUSED, RBD_MINV_PHASE_A_IA8,
+                                       RBD_MINV_PHASE_A_LANE, RBD_OPT_MINV_PHASE_A)
     from oracle import rbd_oracle as orc
     g = load_golden(name); rbd = rbd_for(name)
     if int(rbd._lib.lib.rbd_minv_workspace_bytes(64, 4)) == 0:
@@ -622,8 +624,12 @@ def test_minv_both_phase_a_kernels(name):
     rng = np.random.default_rng(9)
     qr = rng.uniform(-np.pi, np.pi, (777, rbd.n))
     ref = orc.minv(om, qr)
+    qdr = rng.uniform(-1, 1, (41, rbd.n)); ur = rng.uniform(-1, 1, (41, rbd.n))
+    fdg_ref = orc.forward_dynamics_grad(om, qr[:41], qdr, ur)
+    if name in ("atlas_like", "random_limbs_n14"):
+        assert "minv_fused_kernel" in rbd._lib.kernel_name(2, 4, 777)
     try:
-        for mode in (RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8):
+        for mode in (RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8, RBD_MINV_PHASE_A_FUSED):
             rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, mode)
             for dt, tol in ((torch.float32, TOL32), (torch.float64, TOL64)):
                 (q,) = dev_tensors(dt, g["q"])
@@ -631,6 +637,11 @@ def test_minv_both_phase_a_kernels(name):
                 check("Minv_upper", rbd.minv(q, output_dense=False), np.triu(g["Minv_upper"]), tol)
                 (q2,) = dev_tensors(dt, qr)
                 check("Minv ragged", rbd.minv(q2), ref, tol)
+            # the kernels' qdd = Minv (u - c) epilogue, through forward_dynamics_grad (rnea -> minv + product -> rnea_grad)
+            q2, qd2, u2 = dev_tensors(torch.float64, qr[:41], qdr, ur)
+            got_dq, got_dqd = rbd.forward_dynamics_grad(q2, qd2, u2)
+            check("forward_dynamics_grad dq ragged", got_dq, fdg_ref[0], 1e-8)
+            check("forward_dynamics_grad dqd ragged", got_dqd, fdg_ref[1], 1e-8)
     finally:
         rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, RBD_MINV_PHASE_A_AUTO)
 

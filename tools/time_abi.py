@@ -8,10 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np, torch
 from rbdreference_amd import RBDReference, builtin_robot
 from rbdreference_amd._lib import (RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO, RBD_RNEA_KERNEL_BATCH, RBD_RNEA_KERNEL_GROUPS,
-                                   RBD_OPT_MINV_PHASE_A, RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8)
+                                   RBD_OPT_MINV_PHASE_A, RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8,
+                                   RBD_MINV_PHASE_A_FUSED)
 name = os.environ.get("ROBOT", "atlas_like"); B = int(os.environ.get("B", "16384"))
 dt = torch.float64 if os.environ.get("DTYPE", "f32") == "f64" else torch.float32
-rbd = RBDReference(builtin_robot(name), build=False); n = rbd.n
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from conftest import make_robot
+rbd = RBDReference(make_robot(name), build=False); n = rbd.n
 rng = np.random.default_rng(2)
 q, qd, qdd = (torch.tensor(x, dtype=dt, device="cuda") for x in (rng.uniform(-np.pi, np.pi, (B, n)), rng.uniform(-1, 1, (B, n)), rng.uniform(-1, 1, (B, n))))
 c = torch.empty((B, n), dtype=dt, device="cuda"); v = torch.empty((B, 6, n), dtype=dt, device="cuda"); a = torch.empty_like(v); f = torch.empty_like(v)
@@ -42,7 +45,7 @@ for nm, opt in (("auto", RBD_RNEA_KERNEL_AUTO), ("batch", RBD_RNEA_KERNEL_BATCH)
 rbd._lib.set_option(RBD_OPT_RNEA_KERNEL, RBD_RNEA_KERNEL_AUTO)
 us = t(lambda: frnea(q.data_ptr(), qd.data_ptr(), qdd.data_ptr(), -9.81, B, c.data_ptr(), None, None, None, st))
 print(f"{name} rnea (c only)   B={B}        : {us:7.2f} us")
-for nm, opt in (("auto", RBD_MINV_PHASE_A_AUTO), ("lane", RBD_MINV_PHASE_A_LANE), ("ia8", RBD_MINV_PHASE_A_IA8)):
+for nm, opt in (("auto", RBD_MINV_PHASE_A_AUTO), ("lane", RBD_MINV_PHASE_A_LANE), ("ia8", RBD_MINV_PHASE_A_IA8), ("fused", RBD_MINV_PHASE_A_FUSED)):
     rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, opt)
     us = t(lambda: fminv(q.data_ptr(), B, 1, M.data_ptr(), ws.data_ptr(), wsb, st), 100)
     print(f"{name} minv dense      B={B} {nm:7s}: {us:7.2f} us   {B * (n + n * n) * esz / us / 1e3:7.1f} GB/s")
