@@ -59,7 +59,7 @@ int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gra
     if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
     const bool vaf = v || a || f;
     if (vaf && !(v && a && f && c)) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: c, v, a, f must be all non-null");
-    const int64_t blocks = (B + 63) / 64;
+    const int64_t blocks = (B + FB_GRAD_C - 1) / FB_GRAD_C;
     if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
     if (vaf) {   // RBDReference.rnea's outputs: the rnea kernel's own launch
       int rc = rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);
@@ -78,7 +78,7 @@ int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
   if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
-  const int64_t blocks = (B + 63) / 64;
+  const int64_t blocks = (B + 64 / FB_MINV_L - 1) / (64 / FB_MINV_L);
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   hipLaunchKernelGGL((minv_fb_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, dense, Minv);
   hipError_t e = hipGetLastError();
