@@ -1177,6 +1177,21 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
         done = true;
       }
     }
+    if constexpr (RW % VE == 0 && GRAD_TS % VE == 0 && GRAD_TILE % VE == 0 && (row0 * GRAD_ROW) % VE == 0) {
+      // rows of one group among several, or a ragged tile: still 16-byte pieces (a configuration's segment of RW
+      // scalars and its LDS row both start on 16-byte boundaries)
+      if (!done) {
+        typedef T V __attribute__((ext_vector_type(VE)));
+        constexpr int RV = RW / VE;
+#pragma unroll 4
+        for (int g = lane; g < nvalid * RV; g += NT) {
+          const int cfg = g / RV;
+          const int r = g - cfg * RV;
+          *reinterpret_cast<V*>(gdst + cfg * GRAD_TILE + r * VE) = *reinterpret_cast<const V*>(tile + cfg * GRAD_TS + r * VE);
+        }
+        done = true;
+      }
+    }
     if (!done) {
 #pragma unroll 4
       for (int g = lane; g < nvalid * RW; g += NT) {
@@ -2085,6 +2100,7 @@ int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_
   constexpr int CFGS = grad_cfgs<T>();
   const int64_t blocks = (B + CFGS - 1) / CFGS;
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+  if ((reinterpret_cast<uintptr_t>(dc_du) & 15u) != 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: dc_du must be 16-byte aligned");
   const size_t lds = sizeof(T) * ((size_t)CFGS * GRAD_TS + (FDG ? (size_t)CFGS * N * N : 0));
   if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
   auto k = rnea_grad_kernel<T, HAS_QDD, FDG>;
