@@ -17,6 +17,10 @@
  *   - no C++ exceptions cross this boundary; the model is immutable, so concurrent calls from
  *     several host threads / streams are safe.
  *
+ * Output buffers (c, v, a, f, dc_du, Minv, qdd, ...) and workspaces must be 16-byte aligned -- any device
+ * allocation is; a view into the middle of one may not be -- the kernels store 16-byte pieces.  A misaligned
+ * output is refused with RBD_ERR_ARG.  Inputs may have any alignment of their element type.
+ *
  * Floating-base robots (RBDReference.py:585-593, :652-691, :761-779; robot.floating_base): body 0
  * owns indices 0..5 of q, qd, qdd, c (q[0:6] = px, py, pz, rx, ry, rz of the world -> base transform,
  * qd[0:6] = the base twist in base coordinates), body i >= 1 owns index i + 5; "n" in the shapes

@@ -1992,6 +1992,8 @@ int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* 
   if (fpass_only && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea_fpass: v, a, f must be non-null");
   const bool vaf = v || a || f;
   if (vaf && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea: v, a, f must be all null or all non-null");
+  if (((reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(f)) & 15u) != 0)
+    return fail(RBD_ERR_ARG, "rbd_rnea: output buffers must be 16-byte aligned");
   const int64_t blocks = (B + 63) / 64;
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea: B too large");
   hipStream_t s = (hipStream_t)stream;
@@ -2216,6 +2218,8 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
   if (B == 0) return 0;
   if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
+  if (((reinterpret_cast<uintptr_t>(dc_du) | reinterpret_cast<uintptr_t>(c)) & 15u) != 0)
+    return fail(RBD_ERR_ARG, "rbd_rnea_grad: output buffers must be 16-byte aligned");
   if (qdd) return rnea_grad_launch_q<T, true>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
   return rnea_grad_launch_q<T, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
 }
@@ -2228,6 +2232,9 @@ int rnea_with_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int 
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: B < 0");
   if (B == 0) return 0;
   if (!q || !qd || !c || !v || !a || !f || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: q, qd, c, v, a, f, dc_du must be non-null");
+  if (((reinterpret_cast<uintptr_t>(dc_du) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(a) |
+        reinterpret_cast<uintptr_t>(f)) & 15u) != 0)
+    return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: output buffers must be 16-byte aligned");
   if (grad_use_cols<T>(B)) {
     if (qdd) return grad_cols_launch<T, true>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
     return grad_cols_launch<T, false>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
@@ -2265,6 +2272,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
   if (!q || (!Minv && !qdd)) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  if ((reinterpret_cast<uintptr_t>(Minv) & 15u) != 0) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be 16-byte aligned");
   if constexpr (MINV_USE_LANE) {
     // fused one-lane-per-configuration kernel (rbd_minv_lane.h): no workspace
     const int64_t blocks = (B + 63) / 64;

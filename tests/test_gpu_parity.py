@@ -262,6 +262,15 @@ def test_argument_errors():
     with pytest.raises(RbdError) as ei:
         rbd._lib.check(rbd._lib.lib.rbd_rnea_grad_f32(q.data_ptr(), q.data_ptr(), None, -9.81, 0, 4, None, None, None))
     assert ei.value.code == RBD_ERR_ARG
+    # ... and output buffers that are not 16-byte aligned (include/rbd_hip.h: the kernels store 16-byte pieces)
+    buf = torch.zeros(4 * 7 * 14 + 4 * 7 * 7 + 8, device="cuda:0")
+    off = buf.data_ptr() + 4                                   # 4 bytes into an allocation
+    for call in (lambda: rbd._lib.lib.rbd_rnea_grad_f32(q.data_ptr(), q.data_ptr(), None, -9.81, 0, 4, None, off, None),
+                 lambda: rbd._lib.lib.rbd_rnea_f32(q.data_ptr(), q.data_ptr(), None, -9.81, 4, off, None, None, None, None),
+                 lambda: rbd._lib.lib.rbd_minv_f32(q.data_ptr(), 4, 1, off, None, 0, None)):
+        with pytest.raises(RbdError) as ei:
+            rbd._lib.check(call())
+        assert ei.value.code == RBD_ERR_ARG and "aligned" in str(ei.value)
     # B = 0 is a no-op
     e = torch.zeros((0, 7), device="cuda:0")
     assert rbd.rnea_grad(e, e, e).shape == (0, 7, 14)
