@@ -81,16 +81,35 @@ class RBDReference:
             t = t[0]
         return t.cpu().numpy() if is_np else t
 
+    @staticmethod
+    def _check_out(t, shape, dev, dt, name):
+        """A caller-provided output tensor (`out=`): right shape, dtype, device, contiguous."""
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dt or t.device != dev or not t.is_contiguous():
+            raise ValueError(f"out: `{name}` must be a contiguous {dt} tensor of shape {tuple(shape)} on {dev}")
+        return t
+
     def _fn(self, base: str, dt):
         return getattr(self._lib.lib, f"{base}_{'f32' if dt == torch.float32 else 'f64'}")
 
     # ------------------------------------------------------------------------------------
-    def rnea(self, q, qd, qdd=None, GRAVITY=-9.81, f_ext=None, outputs: str = "cvaf"):
+    def rnea(self, q, qd, qdd=None, GRAVITY=-9.81, f_ext=None, outputs: str = "cvaf", out=None):
         """RBDReference.rnea (``RBDReference.py:623-628``) -> ``(c, v, a, f)``; ``f`` is the
         accumulated force, ``f_ext`` is accepted and ignored exactly as there.
-        ``outputs="c"`` skips v, a, f (returns ``(c, None, None, None)``)."""
+        ``outputs="c"`` skips v, a, f (returns ``(c, None, None, None)``).  ``out=(c, v, a, f)``: write into these
+        pre-allocated device tensors (batched tensor inputs only) -- a loop that owns its buffers then pays the
+        launch alone, not four allocations per call."""
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
+        if out is not None:
+            if is_np or unb or outputs != "cvaf" or len(out) != 4:
+                raise ValueError("out= needs batched tensor inputs, outputs='cvaf' and four tensors (c, v, a, f)")
+            c = self._check_out(out[0], (B, self.nv), dev, dt, "c")
+            v, a, f = (self._check_out(t, (B, 6, self.n), dev, dt, nm) for t, nm in zip(out[1:], "vaf"))
+            with torch.cuda.device(dev):
+                self._lib.check(self._fn("rbd_rnea", dt)(
+                    self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY), B,
+                    self._ptr(c), self._ptr(v), self._ptr(a), self._ptr(f), torch.cuda.current_stream(dev).cuda_stream))
+            return c, v, a, f
         with torch.cuda.device(dev):
             c = torch.empty((B, self.nv), device=dev, dtype=dt)
             if outputs == "cvaf":
@@ -286,7 +305,7 @@ class RBDReference:
         return self._ret(Mw, unb, is_np)
 
     def rnea_grad(self, q, qd, qdd=None, GRAVITY=-9.81, USE_VELOCITY_DAMPING=False,
-                  return_c: bool = False):
+                  return_c: bool = False, out=None):
         """RBDReference.rnea_grad (``RBDReference.py:1345-1368``) -> ``dc_du = [dc_dq | dc_dqd]``,
         ``(n, 2n)`` per configuration.  ``return_c=True`` also returns the bias force ``c`` the
         reference computes internally (``:1353``) -> ``(c, dc_du)``.  Floating base: ``n = NB + 5`` and the
@@ -294,6 +313,17 @@ class RBDReference:
         with fewer than six bodies are refused (the reference raises IndexError for them, ``:1168``)."""
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
+        if out is not None:      # out=dc_du, or out=(c, dc_du) with return_c=True: pre-allocated device tensors
+            if is_np or unb:
+                raise ValueError("out= needs batched tensor inputs")
+            oc, odc = (out if return_c else (None, out))
+            dc = self._check_out(odc, (B, self.nv, 2 * self.nv), dev, dt, "dc_du")
+            c = self._check_out(oc, (B, self.nv), dev, dt, "c") if return_c else None
+            with torch.cuda.device(dev):
+                self._lib.check(self._fn("rbd_rnea_grad", dt)(
+                    self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B,
+                    self._ptr(c), self._ptr(dc), torch.cuda.current_stream(dev).cuda_stream))
+            return (c, dc) if return_c else dc
         with torch.cuda.device(dev):
             dc = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
             c = torch.empty((B, self.nv), device=dev, dtype=dt) if return_c else None
@@ -323,21 +353,35 @@ class RBDReference:
                 self._ptr(c), self._ptr(v), self._ptr(a), self._ptr(f), self._ptr(dc), st))
         return tuple(self._ret(t, unb, is_np) for t in (c, v, a, f, dc))
 
-    def minv(self, q, output_dense=True):
+    def minv(self, q, output_dense=True, out=None, workspace=None):
         """RBDReference.minv (``RBDReference.py:785-806``) -> ``(n, n)`` per configuration.
         ``output_dense=False`` returns the upper triangle with a ZERO strict lower triangle (the
-        reference leaves forward-pass by-products there, ``:771``)."""
+        reference leaves forward-pass by-products there, ``:771``).  ``out=`` / ``workspace=``: a pre-allocated
+        ``[B, n, n]`` result tensor and a uint8 scratch tensor of ``minv_workspace_bytes(B, dtype)`` bytes
+        (batched tensor input only), for loops that own their buffers."""
         (q,), unb, is_np, dev, dt = self._prep(q)
         B = q.shape[0]
         esz = 4 if dt == torch.float32 else 8
+        if out is not None and (is_np or unb):
+            raise ValueError("out= needs a batched tensor input")
         with torch.cuda.device(dev):
-            M = torch.empty((B, self.nv, self.nv), device=dev, dtype=dt)
+            M = torch.empty((B, self.nv, self.nv), device=dev, dtype=dt) if out is None else \
+                self._check_out(out, (B, self.nv, self.nv), dev, dt, "Minv")
             wsb = int(self._lib.lib.rbd_minv_workspace_bytes(B, esz))
-            ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
+            if workspace is not None:
+                if workspace.dtype != torch.uint8 or workspace.device != dev or workspace.numel() < wsb or not workspace.is_contiguous():
+                    raise ValueError(f"workspace: a contiguous uint8 tensor of >= {wsb} bytes on {dev}")
+                ws = workspace
+            else:
+                ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
             st = torch.cuda.current_stream(dev).cuda_stream
             self._lib.check(self._fn("rbd_minv", dt)(
                 self._ptr(q), B, 1 if output_dense else 0, self._ptr(M), ws.data_ptr(), wsb, st))
         return self._ret(M, unb, is_np)
+
+    def minv_workspace_bytes(self, B: int, dtype=torch.float32) -> int:
+        """Scratch bytes ``minv`` needs for B rows (0 for robots served by a kernel without workspace)."""
+        return int(self._lib.lib.rbd_minv_workspace_bytes(int(B), 4 if dtype == torch.float32 else 8))
 
     def crba(self, q):
         """RBDReference.crba (fixed-base branch, ``RBDReference.py:1091-1124``) -> joint-space inertia

@@ -277,6 +277,36 @@ def test_argument_errors():
     assert rbd.minv(e).shape == (0, 7, 7)
 
 
+def test_preallocated_outputs():
+    """`out=` / `workspace=`: the Python class writes into caller-owned device tensors (same kernels, no allocation)."""
+    torch = _torch()
+    for name in ("iiwa_like", "atlas_like"):
+        rbd = rbd_for(name)
+        g = load_golden(name)
+        q, qd, qdd = dev_tensors(torch.float32, g["q"], g["qd"], g["qdd"])
+        B, n = q.shape
+        ref = rbd.rnea(q, qd, qdd)
+        bufs = (torch.empty((B, n), device="cuda:0"), torch.empty((B, 6, n), device="cuda:0"),
+                torch.empty((B, 6, n), device="cuda:0"), torch.empty((B, 6, n), device="cuda:0"))
+        got = rbd.rnea(q, qd, qdd, out=bufs)
+        assert all(x is y for x, y in zip(got, bufs)) and all(torch.equal(x, y) for x, y in zip(got, ref))
+        dc = torch.empty((B, n, 2 * n), device="cuda:0"); c = torch.empty((B, n), device="cuda:0")
+        assert rbd.rnea_grad(q, qd, qdd, out=dc) is dc and torch.equal(dc, rbd.rnea_grad(q, qd, qdd))
+        c2, dc2 = rbd.rnea_grad(q, qd, qdd, return_c=True, out=(c, dc))
+        assert c2 is c and dc2 is dc and torch.allclose(c, ref[0], rtol=1e-4, atol=1e-4)   # (the gradient kernel's own c)
+        M = torch.empty((B, n, n), device="cuda:0")
+        ws = torch.empty((max(rbd.minv_workspace_bytes(B), 16),), dtype=torch.uint8, device="cuda:0")
+        assert rbd.minv(q, out=M, workspace=ws) is M and torch.equal(M, rbd.minv(q))
+        with pytest.raises(ValueError):
+            rbd.rnea(q, qd, qdd, out=(bufs[0], bufs[1], bufs[2]))              # three tensors
+        with pytest.raises(ValueError):
+            rbd.rnea_grad(q, qd, qdd, out=dc.double())                          # wrong dtype
+        with pytest.raises(ValueError):
+            rbd.minv(q, out=M[:, :, : n - 1])                                   # wrong shape
+        with pytest.raises(ValueError):
+            rbd.minv(g["q"], out=M)                                              # numpy input
+
+
 def test_noncontiguous_inputs_are_handled():
     torch = _torch()
     rbd = rbd_for("iiwa_like")
