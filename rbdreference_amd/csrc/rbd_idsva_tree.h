@@ -38,6 +38,13 @@ struct TreePlan {
   int park[N > 0 ? N : 1] = {};      // slot of the parked composite (heads with a parent)
   int cross0[N > 0 ? N : 1] = {};    // number of cross pairs (x, y) with y < j
   int rootidx[N > 0 ? N : 1] = {};   // index of the body's root among the roots (0, 1, ...)
+  int side_head[N > 0 ? N : 1] = {}; // per ROOT INDEX: head of the side subtree that runs on the block's second wave, -1: none
+  bool on_side[N > 0 ? N : 1] = {};  // body belongs to its root's side subtree
+  bool any_side = false;
+  int wave_of[N > 0 ? N : 1] = {};   // wave (of a one-block-per-64-configurations layout) that runs the body's chain
+  int wave_len[16] = {};             // longest chain of a wave
+  int inch_off[17] = {};             // first in-chain pending slot of a wave (prefix sums of L (L - 1))
+  int n_waves = 0;
   int n_cross = 0, n_park = 0, max_len = 0, n_roots = 0;
   constexpr TreePlan() {
     for (int i = 0; i < N; ++i) rootidx[i] = PARENT[i] < 0 ? n_roots++ : rootidx[PARENT[i]];
@@ -69,6 +76,41 @@ struct TreePlan {
       cross0[j] = n_cross;
       for (int x = PARENT[j]; x >= 0; x = PARENT[x])
         if (head[x] != head[j]) ++n_cross;
+    }
+    // the side subtree of a root: the biggest chain-head subtree (>= TREE_SIDE_MIN bodies) hanging directly off
+    // the root's heavy chain; it depends on nothing outside itself but the root path's kinematics (recomputed) and
+    // is needed only when the heavy chain's upward sweep reaches its parent
+    for (int r = 0; r < N; ++r) side_head[r] = -1;
+    for (int h = 0; h < N; ++h) {
+      const int p = PARENT[h];
+      if (head[h] != h || p < 0) continue;
+      int rt = h;
+      while (PARENT[rt] >= 0) rt = PARENT[rt];
+      if (head[p] != rt) continue;                       // parent is not on the root's heavy chain
+      if (sub[h] < 4) continue;
+      const int ri = rootidx[h];
+      if (side_head[ri] < 0 || sub[h] > sub[side_head[ri]]) side_head[ri] = h;
+    }
+    for (int j = 0; j < N; ++j) {
+      const int sh = side_head[rootidx[j]];
+      bool in = false;
+      if (sh >= 0)
+        for (int x = j; x >= 0; x = PARENT[x])
+          if (x == sh) in = true;
+      on_side[j] = in;
+      any_side = any_side || in;
+    }
+    // waves: per root (in index order) its main wave, then its side wave if it has one
+    {
+      int base[N > 0 ? N : 1] = {};
+      int w = 0;
+      for (int r = 0; r < N; ++r)
+        if (PARENT[r] < 0) { base[rootidx[r]] = w; w += 1 + (side_head[rootidx[r]] >= 0 ? 1 : 0); }
+      n_waves = w;
+      for (int j = 0; j < N; ++j) wave_of[j] = base[rootidx[j]] + (on_side[j] ? 1 : 0);
+      for (int j = 0; j < N; ++j)
+        if (head[j] == j && wave_of[j] < 16 && len[j] > wave_len[wave_of[j]]) wave_len[wave_of[j]] = len[j];
+      for (int k = 0; k < 16; ++k) inch_off[k + 1] = inch_off[k] + wave_len[k] * (wave_len[k] - 1);
     }
   }
 };
@@ -102,16 +144,24 @@ constexpr int TREE_KP = (N % 2 == 0) ? 4 * ((N / 2) | 1) : 2 * N;
 constexpr int TREE_KP2 = TREE_KP / 2;
 constexpr int TREE_COMP = 31;
 constexpr int TREE_INCH = 0;
-constexpr int TREE_CROSS = TREE_INCH + max_chain_len() * (max_chain_len() - 1);
+// Robots with a side subtree (Atlas' right arm next to the heavy path back -> left arm): ONE block per 64
+// configurations, one wave per root subtree plus one per side subtree, each with its own row image and its own
+// in-chain pending region (sized by its longest chain).  Other robots: one single-wave block per (64 configurations,
+// root), blockIdx.y = root, as before.
+constexpr int TREE_MULTI_SCALARS = TP.n_waves * TREE_KP + TP.inch_off[TP.n_waves < 16 ? TP.n_waves : 16] + 2 * TP.n_cross + 31 * TP.n_park;
+constexpr bool TREE_MULTI = TP.any_side && TP.n_waves <= 8 && (size_t)64 * TREE_MULTI_SCALARS * (N <= 12 ? 8 : 4) <= 156 * 1024;
+constexpr int TREE_W = TREE_MULTI ? TP.n_waves : 1;
+constexpr int TREE_INCH_TOTAL = TREE_MULTI ? TP.inch_off[TP.n_waves] : max_chain_len() * (max_chain_len() - 1);
+constexpr int TREE_CROSS = TREE_INCH + TREE_INCH_TOTAL;
 constexpr int TREE_PARK = TREE_CROSS + 2 * n_cross_pairs();
 constexpr int TREE_PRIV = TREE_PARK + TREE_COMP * n_parked_chains();
 template <class T>
-constexpr size_t tree_lds_bytes() { return sizeof(T) * (size_t)64 * (TREE_KP + TREE_PRIV); }
+constexpr size_t tree_lds_bytes() { return sizeof(T) * (size_t)64 * (TREE_W * TREE_KP + TREE_PRIV); }
 
 constexpr int tree_pend_slot(int jj, int j) {   // slot of the (dq, dqd) pair for row jj, column j
   if (chain_head_of(jj) == chain_head_of(j)) {
     const int a = pos_in_chain(jj), b = pos_in_chain(j);
-    return TREE_INCH + 2 * (b * (b - 1) / 2 + a);
+    return TREE_INCH + (TREE_MULTI ? TP.inch_off[TP.wave_of[j]] : 0) + 2 * (b * (b - 1) / 2 + a);
   }
   return TREE_CROSS + 2 * cross_rank(jj, j);
 }
@@ -348,13 +398,13 @@ RBD_DEV void comp_each(Comp<T>& c, F&& f) {
 }
 
 template <class T, bool HAS_QDD>
-__global__ __launch_bounds__(64, 1) void rnea_grad_tree_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+__global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                                const T* __restrict__ qdd, T grav, int use_damping,
                                                                long long B, T* __restrict__ c_out, T* __restrict__ dcdu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* rowimg = reinterpret_cast<T*>(smem_raw);             // [64][TREE_KP]
-  const int lane = threadIdx.x;
-  T* priv = rowimg + 64 * TREE_KP + lane;                 // priv[slot * 64]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T* rowimg = reinterpret_cast<T*>(smem_raw) + wave * (64 * TREE_KP);   // [64][TREE_KP], one image per wave
+  T* priv = reinterpret_cast<T*>(smem_raw) + TREE_W * 64 * TREE_KP + lane;   // priv[slot * 64], shared by the waves (same lane = same configuration)
   const long long cfg0 = (long long)blockIdx.x * 64;
   const long long rem = B - cfg0;
   const int nvalid = rem < 64 ? (int)rem : 64;
@@ -372,13 +422,15 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_tree_kernel(const T* __restri
   constexpr int CPI = 64 / FW > 0 ? 64 / FW : 1;          // configurations per flush step
   const int fsub = lane / FW, fe = lane - fsub * FW;
   const bool factive = lane < CPI * FW;
-  const int myroot = blockIdx.y;                          // independent root subtrees run in separate blocks
+  const int myroot = blockIdx.y;                          // (single-wave layout) independent root subtrees run in separate blocks
 
   sfor_down<0, N>([&](auto H_) {
     constexpr int h = decltype(H_)::value;
     if constexpr (is_chain_head(h)) {
      constexpr int hroot = TP.rootidx[h];
-     if (hroot == myroot) {
+     constexpr int hwave = TREE_MULTI ? TP.wave_of[h] : 0;  // multi-wave layout: the wave that runs this chain
+     constexpr int side = TREE_MULTI ? TP.side_head[hroot] : -1;
+     if (TREE_MULTI ? (wave == hwave) : (hroot == myroot)) {
       constexpr int leaf = chain_leaf(h);
       // ---- inputs and trig of the root path of this chain ------------------------------------------
       JTrig<T> tr[N];
@@ -409,6 +461,10 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_tree_kernel(const T* __restri
             Comp<T> L;
             comp_local<j>(s, L);
             comp_add(C, L);
+          }
+          // the side subtree (other wave) must have parked its composite and column entries before its parent is built
+          if constexpr (side >= 0 && !TP.on_side[h]) {
+            if constexpr (j == PARENT[side >= 0 ? side : 0]) __syncthreads();
           }
           // finished chains hanging off this body (:1446-1448)
           sfor<0, N>([&](auto K_) {
@@ -524,6 +580,20 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_tree_kernel(const T* __restri
      }
     }
   });
+  if constexpr (TREE_MULTI) {
+    // every wave passes exactly ONE block barrier: a root's main wave before it builds the side subtree's parent
+    // (above), every other wave here, when its chains are done
+    bool main_with_side = false;
+    sfor<0, N>([&](auto R_) {
+      constexpr int r = decltype(R_)::value;
+      if constexpr (PARENT[r] < 0) {
+        constexpr int w0 = TP.wave_of[r];
+        constexpr bool hs = TP.side_head[TP.rootidx[r]] >= 0;
+        if (wave == w0 && hs) main_with_side = true;
+      }
+    });
+    if (!main_with_side) __syncthreads();
+  }
 }
 
 }  // namespace rbdk

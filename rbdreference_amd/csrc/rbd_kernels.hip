@@ -2196,7 +2196,7 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
       int rc;
       auto k = rnea_grad_tree_kernel<T, HAS_QDD>;
       if ((rc = ensure_lds(k, lds)) != 0) return rc;
-      hipLaunchKernelGGL(k, dim3((unsigned)blocks, tree_n_roots()), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks, TREE_MULTI ? 1 : tree_n_roots()), dim3(64 * TREE_W), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, c, dc_du);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad (tree kernel) launch");
       return 0;
