@@ -1820,7 +1820,7 @@ __global__ __launch_bounds__(64 * MINV_COLS_W, MINV_COLS_MIN_WAVES) void minv_co
 // One thread per (configuration, output column): its column of dc_du stays in registers (n coalesced
 // loads), the block's Minv matrices are staged in LDS once and read as broadcasts, so global traffic
 // is exactly Minv + dc_du in, dqdd_du out.
-constexpr int FDA_CPB = (256 / (2 * N)) > 0 ? 256 / (2 * N) : 1;     // configurations per block
+constexpr int FDA_CPB = (256 / N) > 0 ? 256 / N : 1;     // configurations per block: N threads each, a thread owns columns c and c + N
 template <class T>
 __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict__ Minv, const T* __restrict__ dcdu,
                                                             long long B, T* __restrict__ out) {
@@ -1834,19 +1834,27 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
     for (int g = threadIdx.x; g < nvalid * N * N; g += 256) Ml[g] = src[g];
   }
   __syncthreads();
-  const int cl = threadIdx.x / (2 * N);
-  const int c = threadIdx.x - cl * (2 * N);
+  const int cl = threadIdx.x / N;
+  const int c = threadIdx.x - cl * N;
   if (cl >= nvalid) return;
   const T* D = dcdu + (cfg0 + cl) * (2 * N * N);
   T* O = out + (cfg0 + cl) * (2 * N * N);
   const T* M = Ml + cl * (N * N);
-  T d[N];
-  sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; d[k] = D[k * 2 * N + c]; });
+  // the dq and the dqd column of the same index share every Minv element read from LDS (the kernel is bound by
+  // those reads: one per FMA with a single column per thread)
+  T d0[N], d1[N];
+  sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; d0[k] = D[k * 2 * N + c]; d1[k] = D[k * 2 * N + N + c]; });
 #pragma clang loop unroll(disable)
   for (int i = 0; i < N; ++i) {
-    T o = T(0);
-    sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(-M[i * N + k], d[k], o); });
-    O[i * 2 * N + c] = o;
+    T o0 = T(0), o1 = T(0);
+    sfor<0, N>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      const T m = M[i * N + k];
+      o0 = fma_(-m, d0[k], o0);
+      o1 = fma_(-m, d1[k], o1);
+    });
+    O[i * 2 * N + c] = o0;
+    O[i * 2 * N + N + c] = o1;
   }
 }
 
