@@ -262,7 +262,28 @@ RBD_DEV T dot6(const T (&x)[6], const T (&y)[6]) {
   return fma_(x[5], y[5], fma_(x[4], y[4], fma_(x[3], y[3], fma_(x[2], y[2], fma_(x[1], y[1], x[0] * y[0])))));
 }
 
-RBD_DEV void sincos_(float q, float* s, float* c) { sincosf(q, s, c); }
+// fp32 sin / cos of a joint angle.  |q| <= 8192: two-constant Cody-Waite reduction by pi/2 (exact under FMA) and the
+// classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]: max abs error 9.2e-8 over the range (numpy
+// emulation, 6 M samples; a correctly rounded result has 3e-8), ~22 instructions against ~45 for sincosf, which
+// carries the Payne-Hanek path for huge arguments.  Larger |q| take sincosf (a branch no lane takes in practice).
+RBD_DEV void sincos_(float q, float* s, float* c) {
+  if (__builtin_expect(__builtin_fabsf(q) > 8192.0f, 0)) { sincosf(q, s, c); return; }
+  const float kf = __builtin_rintf(q * 0.63661977236758134f);                 // q * 2 / pi
+  float r = __builtin_fmaf(-kf, 1.5707963705062866f, q);                      // pi/2 = hi + mid (+ 1.8e-15)
+  r = __builtin_fmaf(-kf, -4.371138828673793e-08f, r);
+  const int k = (int)kf;
+  const float z = r * r;
+  float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+  sp = __builtin_fmaf(sp * z, r, r);
+  float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+  cp = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const bool swap = (k & 1) != 0;
+  const float ss = swap ? cp : sp, cc = swap ? sp : cp;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
 RBD_DEV void sincos_(double q, double* s, double* c) { sincos(q, s, c); }
 
 template <int J, class T>
