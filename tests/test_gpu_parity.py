@@ -277,6 +277,25 @@ def test_argument_errors():
     assert rbd.minv(e).shape == (0, 7, 7)
 
 
+def test_large_joint_angles_take_the_library_sincos():
+    """fp32 sin/cos: own reduction up to |q| = 8192, sincosf beyond (rbd_spatial.h) -- both sides of the switch, with
+    the oracle fed the float32-rounded angles (at |q| ~ 1e4 one fp32 ulp of q is 1e-3 rad)."""
+    torch = _torch()
+    from oracle import rbd_oracle as orc
+    rbd = rbd_for("iiwa_like"); om = orc.model_from_robot(make_robot("iiwa_like"))
+    rng = np.random.default_rng(123)
+    q = rng.uniform(-20000.0, 20000.0, (512, 7)).astype(np.float32)
+    q[:8] = np.array([8191.9, 8192.0, 8192.1, -8192.0, 5000.0, -7000.0, 1e6])[None, :7] * np.ones((8, 1), dtype=np.float32)
+    qd = rng.uniform(-1, 1, (512, 7)).astype(np.float32); qdd = rng.uniform(-1, 1, (512, 7)).astype(np.float32)
+    tq, tqd, tqdd = (torch.tensor(x, device="cuda:0") for x in (q, qd, qdd))
+    c, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    cr, vr, ar, fr = orc.rnea(om, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64))
+    for nm, x, w in (("c", c, cr), ("v", v, vr), ("a", a, ar), ("f", f, fr)):
+        check(nm, x, w, TOL32)
+    check("dc_du", rbd.rnea_grad(tq, tqd, tqdd), orc.rnea_grad(om, q.astype(np.float64), qd.astype(np.float64), qdd.astype(np.float64)), TOL32)
+    check("minv", rbd.minv(tq), orc.minv(om, q.astype(np.float64)), TOL32)
+
+
 def test_preallocated_outputs():
     """`out=` / `workspace=`: the Python class writes into caller-owned device tensors (same kernels, no allocation)."""
     torch = _torch()
