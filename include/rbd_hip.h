@@ -11,7 +11,9 @@
  * Conventions
  *   - every data pointer is a DEVICE pointer to a dense row-major array, batch index outermost;
  *     the caller owns all buffers; nothing is allocated per call;
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous; the
+ *     calling thread's CURRENT device must be the stream's device (as for any HIP launch): per-kernel
+ *     launch attributes and grid sizes are cached per current device;
  *   - return 0 on success, <0 for argument errors (RBD_ERR_*), >0 = hipError_t of a failed launch;
  *     rbd_last_error() returns a thread-local message for the last non-zero return;
  *   - no C++ exceptions cross this boundary; the model is immutable, so concurrent calls from
@@ -171,7 +173,10 @@ int rbd_rnea_with_grad_f64(const double* q, const double* qd, const double* qdd,
  *   triangle as the reference defines it, strict lower triangle ZERO (the reference leaves
  *   by-products of its forward pass there, :771; documented deviation).
  *   workspace: device scratch of at least rbd_minv_workspace_bytes(B, sizeof(T)) bytes, 16-byte
- *   aligned (0 bytes -- and then ignored -- for robots that use the fused one-lane kernel).       */
+ *   aligned.  0 bytes -- and then ignored, NULL is fine -- whenever the kernel selected by the current
+ *   RBD_OPT_MINV_PHASE_A option does not go through HBM (the one-lane kernel of small robots, the
+ *   one-launch kernel that AUTO picks for robots whose big groups have limbs): query it again after
+ *   changing that option.                                                                          */
 size_t rbd_minv_workspace_bytes(int64_t B, int elem_size);
 int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void* workspace,
                  size_t workspace_bytes, void* stream);

@@ -373,10 +373,10 @@ class RBDReference:
                     raise ValueError(f"workspace: a contiguous uint8 tensor of >= {wsb} bytes on {dev}")
                 ws = workspace
             else:
-                ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
+                ws = torch.empty((wsb,), device=dev, dtype=torch.uint8) if wsb > 0 else None   # most robots: no scratch at all
             st = torch.cuda.current_stream(dev).cuda_stream
             self._lib.check(self._fn("rbd_minv", dt)(
-                self._ptr(q), B, 1 if output_dense else 0, self._ptr(M), ws.data_ptr(), wsb, st))
+                self._ptr(q), B, 1 if output_dense else 0, self._ptr(M), ws.data_ptr() if ws is not None else None, wsb, st))
         return self._ret(M, unb, is_np)
 
     def minv_workspace_bytes(self, B: int, dtype=torch.float32) -> int:

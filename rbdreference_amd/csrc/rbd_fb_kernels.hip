@@ -7,9 +7,12 @@
 // RBD_ERR_UNSUPPORTED with a message.  Shapes: q, qd, qdd, c, u [B, NV]; v, a, f [B, 6, N]; Minv [B, NV, NV].
 // Units: -DRBD_TU_FB_F32 / -DRBD_TU_FB_F64 (rbdreference_amd/build.py).
 #include "rbd_fb.h"
+#include "rbd_fb_world.h"
 #include "../../include/rbd_hip.h"
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <cstdint>
 
 static_assert(rbdm::FLOATING_BASE, "rbd_fb_kernels.hip is for floating-base robots");
 
@@ -28,6 +31,18 @@ int unsupported(const char* who) {
   return RBD_ERR_UNSUPPORTED;
 }
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+extern "C" __attribute__((visibility("hidden"))) std::atomic<int>* rbd_option_slot(int option);
+int rbd_option(int option) { return rbd_option_slot(option)->load(std::memory_order_relaxed); }
+
+// dynamic LDS above 64 KB needs the attribute once per kernel
+template <class K>
+int ensure_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? 0 : hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+}
 
 template <class T>
 int rnea_fb_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {
@@ -37,21 +52,45 @@ int rnea_fb_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, 
   if (!q || !qd || !c) return fail(RBD_ERR_ARG, "rbd_rnea: q, qd and c must be non-null");
   const bool vaf = v || a || f;
   if (vaf && !(v && a && f)) return fail(RBD_ERR_ARG, "rbd_rnea: v, a, f must be all null or all non-null");
+  if (misaligned(c) || misaligned(v) || misaligned(a) || misaligned(f)) return fail(RBD_ERR_ARG, "rbd_rnea: output buffers must be 16-byte aligned");
   const int64_t blocks = (B + 63) / 64;
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea: B too large");
-  if (qdd) hipLaunchKernelGGL((rnea_fb_kernel<T, true>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
-  else hipLaunchKernelGGL((rnea_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+  constexpr size_t lds = rnea_fbw_lds_bytes<T>();
+  if constexpr (lds <= 160 * 1024) {
+    // one configuration per lane, outputs through LDS images as flat 16-byte stores (rbd_fb_world.h)
+    int rc;
+    if (qdd) {
+      auto k = rnea_fbw_kernel<T, true>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+    } else {
+      auto k = rnea_fbw_kernel<T, false>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+    }
+  } else {
+    if (qdd) hipLaunchKernelGGL((rnea_fb_kernel<T, true>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+    else hipLaunchKernelGGL((rnea_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, c, v, a, f);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_rnea (floating base) launch");
+}
+// which gradient kernel serves this robot: the world-frame kernel (rbd_fb_world.h) where its identities apply and
+// its LDS plan fits, else the column recursion (rbd_fb.h); RBD_OPT_GRAD_KERNEL = COLS forces the latter
+template <class T>
+bool grad_fb_use_world() {
+  if constexpr (!rbdk::grad_fbw_ok<T>()) return false;
+  if constexpr (!rbdk::grad_fb_ok<T>()) return true;
+  return rbd_option(RBD_OPT_GRAD_KERNEL) != RBD_GRAD_KERNEL_COLS;
 }
 template <class T>
 int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* v,
                    T* a, T* f, T* dc_du, void* stream) {
   using namespace rbdk;
-  if constexpr (!grad_fb_ok<T>()) {
+  if constexpr (!grad_fb_ok<T>() && !grad_fbw_ok<T>()) {
     std::snprintf(rbd_err_buf(), RBD_ERR_LEN,
                   "%s: floating-base rnea_grad needs 6 <= NB (the reference raises IndexError below, RBDReference.py:1168) "
-                  "and 12 NB lanes-columns of LDS; this robot has NB = %d", who, N);
+                  "and an LDS working set that fits; this robot has NB = %d", who, N);
     return RBD_ERR_UNSUPPORTED;
   } else {
     if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B < 0");
@@ -59,15 +98,36 @@ int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gra
     if (!q || !qd || !dc_du) return fail(RBD_ERR_ARG, "rbd_rnea_grad: q, qd and dc_du must be non-null");
     const bool vaf = v || a || f;
     if (vaf && !(v && a && f && c)) return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: c, v, a, f must be all non-null");
-    const int64_t blocks = (B + FB_GRAD_C - 1) / FB_GRAD_C;
-    if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+    if (misaligned(c) || misaligned(dc_du)) return fail(RBD_ERR_ARG, "rbd_rnea_grad: output buffers must be 16-byte aligned");
     if (vaf) {   // RBDReference.rnea's outputs: the rnea kernel's own launch
       int rc = rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);
       if (rc != 0) return rc;
     }
     T* cg = vaf ? nullptr : c;
-    if (qdd) hipLaunchKernelGGL((rnea_grad_fb_kernel<T, true>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
-    else hipLaunchKernelGGL((rnea_grad_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+    if (grad_fb_use_world<T>()) {
+      if constexpr (grad_fbw_ok<T>()) {
+        const int64_t blocks = (B + 63) / 64;
+        if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+        constexpr size_t lds = fbw_lds_bytes<T>();
+        int rc;
+        if (qdd) {
+          auto k = rnea_grad_fbw_kernel<T, true>;
+          if ((rc = ensure_lds(k, lds)) != 0) return rc;
+          hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+        } else {
+          auto k = rnea_grad_fbw_kernel<T, false>;
+          if ((rc = ensure_lds(k, lds)) != 0) return rc;
+          hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+        }
+      }
+    } else {
+      if constexpr (grad_fb_ok<T>()) {
+        const int64_t blocks = (B + FB_GRAD_C - 1) / FB_GRAD_C;
+        if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+        if (qdd) hipLaunchKernelGGL((rnea_grad_fb_kernel<T, true>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+        else hipLaunchKernelGGL((rnea_grad_fb_kernel<T, false>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+      }
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "rbd_rnea_grad (floating base) launch");
   }
@@ -78,6 +138,7 @@ int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
   if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  if (misaligned(Minv)) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be 16-byte aligned");
   const int64_t blocks = (B + 64 / FB_MINV_L - 1) / (64 / FB_MINV_L);
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   hipLaunchKernelGGL((minv_fb_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, dense, Minv);
@@ -92,6 +153,8 @@ int fd_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* q
   if (!q || !qd || !u || !qdd) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: q, qd, u, qdd must be non-null");
   const size_t off_c = 0, off_m = align16((size_t)B * NV * sizeof(T)), total = off_m + align16((size_t)B * NV * NV * sizeof(T));
   if (!workspace || wsb < total) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics: workspace missing or smaller than rbd_fd_workspace_bytes()");
+  if (misaligned(workspace)) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics: workspace must be 16-byte aligned");
+  if (misaligned(qdd)) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: qdd must be 16-byte aligned");
   char* w = reinterpret_cast<char*>(workspace);
   T* c = reinterpret_cast<T*>(w + off_c);
   T* Mi = reinterpret_cast<T*>(w + off_m);
@@ -115,9 +178,19 @@ __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, ch
 __attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f32(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f64(int64_t B, char* buf, size_t len);
 
+__attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f32(void);
+__attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f64(void);
+
 #define RBD_FB_DEFS(SFX, T)                                                                                                 \
-  int rbd_grad_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "rnea_grad_fb_kernel"); return 0; } \
-  int rbd_rnea_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "rnea_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
+  int rbd_minv_needs_ws_##SFX(void) { return 0; }                                                                           \
+  int rbd_grad_kernel_name_##SFX(int64_t, char* buf, size_t len) {                                                          \
+    std::snprintf(buf, len, "%s<%s,true>", grad_fb_use_world<T>() ? "rnea_grad_fbw_kernel" : "rnea_grad_fb_kernel", sizeof(T) == 4 ? "float" : "double"); \
+    return 0;                                                                                                               \
+  }                                                                                                                         \
+  int rbd_rnea_kernel_name_##SFX(int64_t, char* buf, size_t len) {                                                          \
+    std::snprintf(buf, len, "%s<%s,true>", rbdk::rnea_fbw_lds_bytes<T>() <= 160 * 1024 ? "rnea_fbw_kernel" : "rnea_fb_kernel", sizeof(T) == 4 ? "float" : "double"); \
+    return 0;                                                                                                               \
+  }                                                                                                                         \
   int rbd_minv_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "minv_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
   int rbd_rnea_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {   \
     return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \

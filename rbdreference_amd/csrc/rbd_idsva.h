@@ -25,6 +25,7 @@
 // Other robots keep rnea_grad_kernel.
 #pragma once
 #include "rbd_spatial.h"
+#include "rbd_world.h"
 
 namespace rbdk {
 
@@ -45,66 +46,6 @@ constexpr bool grad_idsva_ok_() {
   return grad_max_rows() <= 8;
 }
 constexpr bool GRAD_IDSVA_OK = grad_idsva_ok_();
-
-// ---- small world-frame helpers -------------------------------------------------------------------
-template <class T>
-RBD_DEV void cross3(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
-  o[0] = fma_(a[1], b[2], -(a[2] * b[1]));
-  o[1] = fma_(a[2], b[0], -(a[0] * b[2]));
-  o[2] = fma_(a[0], b[1], -(a[1] * b[0]));
-}
-// o += a x b
-template <class T>
-RBD_DEV void cross3_acc(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
-  o[0] = fma_(a[1], b[2], fma_(-a[2], b[1], o[0]));
-  o[1] = fma_(a[2], b[0], fma_(-a[0], b[2], o[1]));
-  o[2] = fma_(a[0], b[1], fma_(-a[1], b[0], o[2]));
-}
-// motion cross: o = crm(v) x
-template <class T>
-RBD_DEV void crm6(const T (&v)[6], const T (&x)[6], T (&o)[6]) {
-  const T w[3] = {v[0], v[1], v[2]}, u[3] = {v[3], v[4], v[5]};
-  const T xa[3] = {x[0], x[1], x[2]}, xb[3] = {x[3], x[4], x[5]};
-  T oa[3], ob[3];
-  cross3(w, xa, oa);
-  cross3(u, xa, ob);
-  cross3_acc(w, xb, ob);
-  o[0] = oa[0]; o[1] = oa[1]; o[2] = oa[2]; o[3] = ob[0]; o[4] = ob[1]; o[5] = ob[2];
-}
-// rigid-body inertia (m, h, Ibar sym: xx xy xz yy yz zz) times a motion vector
-template <class T>
-struct RInertia {
-  T m, h[3], I[6];
-};
-template <class T>
-RBD_DEV void rin_apply(const RInertia<T>& R, const T (&x)[6], T (&y)[6]) {
-  const T w[3] = {x[0], x[1], x[2]}, u[3] = {x[3], x[4], x[5]};
-  T top[3] = {fma_(R.I[0], w[0], fma_(R.I[1], w[1], R.I[2] * w[2])),
-              fma_(R.I[1], w[0], fma_(R.I[3], w[1], R.I[4] * w[2])),
-              fma_(R.I[2], w[0], fma_(R.I[4], w[1], R.I[5] * w[2]))};
-  cross3_acc(R.h, u, top);
-  T hw[3];
-  cross3(R.h, w, hw);
-  y[0] = top[0]; y[1] = top[1]; y[2] = top[2];
-  y[3] = fma_(R.m, u[0], -hw[0]); y[4] = fma_(R.m, u[1], -hw[1]); y[5] = fma_(R.m, u[2], -hw[2]);
-}
-// Sym = [[TL, G^x], [G^x^T, 0]] times a motion vector: [TL a + G x b ; -G x a]
-template <class T>
-struct SymB {
-  T TL[6], G[3];
-};
-template <class T>
-RBD_DEV void sym_apply(const SymB<T>& S, const T (&x)[6], T (&y)[6]) {
-  const T a[3] = {x[0], x[1], x[2]}, b[3] = {x[3], x[4], x[5]};
-  T top[3] = {fma_(S.TL[0], a[0], fma_(S.TL[1], a[1], S.TL[2] * a[2])),
-              fma_(S.TL[1], a[0], fma_(S.TL[3], a[1], S.TL[4] * a[2])),
-              fma_(S.TL[2], a[0], fma_(S.TL[4], a[1], S.TL[5] * a[2]))};
-  cross3_acc(S.G, b, top);
-  T ga[3];
-  cross3(S.G, a, ga);
-  y[0] = top[0]; y[1] = top[1]; y[2] = top[2];
-  y[3] = -ga[0]; y[4] = -ga[1]; y[5] = -ga[2];
-}
 
 // The block is ONE wave and a wave's LDS operations execute in order: ordering LDS traffic between
 // lanes needs a compiler-level fence only.  __syncthreads() would add s_waitcnt vmcnt(0), i.e. wait

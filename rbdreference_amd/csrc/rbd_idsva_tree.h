@@ -27,112 +27,6 @@
 
 namespace rbdk {
 
-// ---- compile-time chain decomposition (tables, so that constexpr evaluation stays O(n^2)) ---------
-struct TreePlan {
-  int sub[N > 0 ? N : 1] = {};       // subtree size
-  int heavy[N > 0 ? N : 1] = {};     // heavy child or -1
-  int head[N > 0 ? N : 1] = {};      // head of the body's chain
-  int pos[N > 0 ? N : 1] = {};       // position in the chain (0 at the head)
-  int leaf[N > 0 ? N : 1] = {};      // leaf of the chain that starts at a head (valid at heads)
-  int len[N > 0 ? N : 1] = {};       // chain length (valid at heads)
-  int park[N > 0 ? N : 1] = {};      // slot of the parked composite (heads with a parent)
-  int cross0[N > 0 ? N : 1] = {};    // number of cross pairs (x, y) with y < j
-  int rootidx[N > 0 ? N : 1] = {};   // index of the body's root among the roots (0, 1, ...)
-  int side_head[N > 0 ? N : 1] = {}; // per ROOT INDEX: head of the side subtree that runs on the block's second wave, -1: none
-  bool on_side[N > 0 ? N : 1] = {};  // body belongs to its root's side subtree
-  bool any_side = false;
-  int wave_of[N > 0 ? N : 1] = {};   // wave (of a one-block-per-64-configurations layout) that runs the body's chain
-  int wave_len[16] = {};             // longest chain of a wave
-  int inch_off[17] = {};             // first in-chain pending slot of a wave (prefix sums of L (L - 1))
-  int n_waves = 0;
-  int n_cross = 0, n_park = 0, max_len = 0, n_roots = 0;
-  constexpr TreePlan() {
-    for (int i = 0; i < N; ++i) rootidx[i] = PARENT[i] < 0 ? n_roots++ : rootidx[PARENT[i]];
-    for (int i = 0; i < N; ++i) sub[i] = 1;
-    for (int i = N - 1; i >= 0; --i)
-      if (PARENT[i] >= 0) sub[PARENT[i]] += sub[i];
-    for (int i = 0; i < N; ++i) heavy[i] = -1;
-    for (int i = 0; i < N; ++i) {          // lowest index wins ties
-      const int p = PARENT[i];
-      if (p >= 0 && (heavy[p] < 0 || sub[i] > sub[heavy[p]])) heavy[p] = i;
-    }
-    for (int i = 0; i < N; ++i) {
-      const int p = PARENT[i];
-      if (p >= 0 && heavy[p] == i) { head[i] = head[p]; pos[i] = pos[p] + 1; }
-      else { head[i] = i; pos[i] = 0; }
-    }
-    for (int i = 0; i < N; ++i) { leaf[i] = i; len[i] = 0; }
-    for (int i = 0; i < N; ++i) {
-      const int h = head[i];
-      if (pos[i] + 1 > len[h]) { len[h] = pos[i] + 1; leaf[h] = i; }
-    }
-    for (int i = 0; i < N; ++i) {
-      if (head[i] == i) {
-        if (len[i] > max_len) max_len = len[i];
-        if (PARENT[i] >= 0) park[i] = n_park++;
-      }
-    }
-    for (int j = 0; j < N; ++j) {
-      cross0[j] = n_cross;
-      for (int x = PARENT[j]; x >= 0; x = PARENT[x])
-        if (head[x] != head[j]) ++n_cross;
-    }
-    // the side subtree of a root: the biggest chain-head subtree (>= TREE_SIDE_MIN bodies) hanging directly off
-    // the root's heavy chain; it depends on nothing outside itself but the root path's kinematics (recomputed) and
-    // is needed only when the heavy chain's upward sweep reaches its parent
-    for (int r = 0; r < N; ++r) side_head[r] = -1;
-    for (int h = 0; h < N; ++h) {
-      const int p = PARENT[h];
-      if (head[h] != h || p < 0) continue;
-      int rt = h;
-      while (PARENT[rt] >= 0) rt = PARENT[rt];
-      if (head[p] != rt) continue;                       // parent is not on the root's heavy chain
-      if (sub[h] < 4) continue;
-      const int ri = rootidx[h];
-      if (side_head[ri] < 0 || sub[h] > sub[side_head[ri]]) side_head[ri] = h;
-    }
-    for (int j = 0; j < N; ++j) {
-      const int sh = side_head[rootidx[j]];
-      bool in = false;
-      if (sh >= 0)
-        for (int x = j; x >= 0; x = PARENT[x])
-          if (x == sh) in = true;
-      on_side[j] = in;
-      any_side = any_side || in;
-    }
-    // waves: per root (in index order) its main wave, then its side wave if it has one
-    {
-      int base[N > 0 ? N : 1] = {};
-      int w = 0;
-      for (int r = 0; r < N; ++r)
-        if (PARENT[r] < 0) { base[rootidx[r]] = w; w += 1 + (side_head[rootidx[r]] >= 0 ? 1 : 0); }
-      n_waves = w;
-      for (int j = 0; j < N; ++j) wave_of[j] = base[rootidx[j]] + (on_side[j] ? 1 : 0);
-      for (int j = 0; j < N; ++j)
-        if (head[j] == j && wave_of[j] < 16 && len[j] > wave_len[wave_of[j]]) wave_len[wave_of[j]] = len[j];
-      for (int k = 0; k < 16; ++k) inch_off[k + 1] = inch_off[k] + wave_len[k] * (wave_len[k] - 1);
-    }
-  }
-};
-constexpr TreePlan TP{};
-constexpr bool is_chain_head(int i) { return TP.head[i] == i; }
-constexpr int chain_head_of(int i) { return TP.head[i]; }
-constexpr int chain_leaf(int h) { return TP.leaf[h]; }
-constexpr bool in_chain(int j, int h) { return TP.head[j] == h; }
-constexpr int pos_in_chain(int j) { return TP.pos[j]; }
-constexpr int max_chain_len() { return TP.max_len; }
-// (jj, j): jj a proper ancestor of j in ANOTHER chain; rank = position among all such pairs
-constexpr int cross_rank(int jj, int j) {
-  int k = TP.cross0[j];
-  for (int x = PARENT[j]; x >= 0 && x != jj; x = PARENT[x])
-    if (TP.head[x] != TP.head[j]) ++k;
-  return k;
-}
-constexpr int n_cross_pairs() { return TP.n_cross; }
-constexpr int park_rank(int h) { return TP.park[h]; }
-constexpr int n_parked_chains() { return TP.n_park; }
-constexpr int tree_n_roots() { return TP.n_roots; }
-
 // ---- LDS plan (scalars of T) -----------------------------------------------------------------------
 // [0, 64 * TREE_KP)                      row image, 64 configurations x 2n (+ pad), float2-granular
 // then lane-private columns (slot * 64 + lane):
@@ -142,7 +36,7 @@ constexpr int tree_n_roots() { return TP.n_roots; }
 // row stride: odd in units of the flush vector (float4 when n is even, else float2) => conflict-free
 constexpr int TREE_KP = (N % 2 == 0) ? 4 * ((N / 2) | 1) : 2 * N;
 constexpr int TREE_KP2 = TREE_KP / 2;
-constexpr int TREE_COMP = 31;
+constexpr int TREE_COMP = TREE_COMP_SCALARS;
 constexpr int TREE_INCH = 0;
 // Robots with a side subtree (Atlas' right arm next to the heavy path back -> left arm): ONE block per 64
 // configurations, one wave per root subtree plus one per side subtree, each with its own row image and its own
@@ -151,6 +45,25 @@ constexpr int TREE_INCH = 0;
 constexpr int TREE_MULTI_SCALARS = TP.n_waves * TREE_KP + TP.inch_off[TP.n_waves < 16 ? TP.n_waves : 16] + 2 * TP.n_cross + 31 * TP.n_park;
 constexpr bool TREE_MULTI = TP.any_side && TP.n_waves <= 8 && (size_t)64 * TREE_MULTI_SCALARS * (N <= 12 ? 8 : 4) <= 156 * 1024;
 constexpr int TREE_W = TREE_MULTI ? TP.n_waves : 1;
+// The multi-wave kernel has ONE block barrier per wave, reached at different program points: a root's main wave
+// reaches it when it gets to the side subtree's parent, every other wave at the end of the kernel.  That is a
+// barrier in wave-divergent control flow; it is sound on gfx9 because s_barrier only COUNTS arrivals, and only if
+// every wave arrives exactly once -- i.e. the side subtree's parent is a body of the main wave's own heavy chain
+// (each body of a chain is processed exactly once).  Checked here for the robot at hand rather than assumed.
+constexpr bool tree_barrier_plan_ok() {
+  for (int r = 0; r < N; ++r) {
+    if (PARENT[r] >= 0) continue;
+    const int sh = TP.side_head[TP.rootidx[r]];
+    if (sh < 0) continue;
+    const int p = PARENT[sh];
+    if (p < 0 || TP.on_side[p]) return false;          // the parent is a body of the MAIN wave ...
+    if (TP.rootidx[p] != TP.rootidx[r]) return false;  // ... of the same root ...
+    if (TP.head[p] != r) return false;                 // ... on the root's heavy chain
+    if (TP.wave_of[p] == TP.wave_of[sh]) return false; // and the side subtree runs on another wave
+  }
+  return true;
+}
+static_assert(!TREE_MULTI || tree_barrier_plan_ok(), "multi-wave tree kernel: a wave would pass its block barrier zero or two times");
 constexpr int TREE_INCH_TOTAL = TREE_MULTI ? TP.inch_off[TP.n_waves] : max_chain_len() * (max_chain_len() - 1);
 constexpr int TREE_CROSS = TREE_INCH + TREE_INCH_TOTAL;
 constexpr int TREE_PARK = TREE_CROSS + 2 * n_cross_pairs();
@@ -174,228 +87,6 @@ constexpr bool grad_tree_ok_() {
   return N >= 2 && N <= 64;
 }
 constexpr bool GRAD_TREE_OK = grad_tree_ok_();
-
-// ---- world-frame state of one body and the sweeps' building blocks -------------------------------
-template <class T>
-struct WState {
-  T R[3][3], p[3], v[6], a[6];   // body -> world rotation, origin, spatial velocity / acceleration (world frame)
-};
-
-// parent(J) -> J  (:1413-1434); for a root the incoming state is ignored
-template <int J, class T>
-RBD_DEV void ws_down(WState<T>& s, const JTrig<T>& g, T qd, T qdd, T grav, T (&Sv)[6], T (&Pd)[6], T (&Pdd)[6]) {
-  constexpr int k = AXIS[J], ka = (k + 1) % 3, kb = (k + 2) % 3;
-  constexpr bool root = PARENT[J] < 0;
-  T Tm[3][3];
-  sfor<0, 3>([&](auto R_) {
-    sfor<0, 3>([&](auto C_) {
-      constexpr int r = decltype(R_)::value, c = decltype(C_)::value;
-      if constexpr (root) {
-        Tm[r][c] = T(Et_(J, c, r));
-      } else {
-        T acc = T(0);
-        sfor<0, 3>([&](auto M_) {
-          constexpr int m = decltype(M_)::value;
-          constexpr double e = Et_(J, c, m);
-          if constexpr (e == 1.0) acc = acc + s.R[r][m];
-          else if constexpr (e == -1.0) acc = acc - s.R[r][m];
-          else if constexpr (e != 0.0) acc = fma_(T(e), s.R[r][m], acc);
-        });
-        Tm[r][c] = acc;
-      }
-    });
-  });
-  T pn[3];
-  sfor<0, 3>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    if constexpr (root) {
-      pn[r] = T(rt_(J, r));
-    } else {
-      T acc = s.p[r];
-      sfor<0, 3>([&](auto M_) {
-        constexpr int m = decltype(M_)::value;
-        constexpr double e = rt_(J, m);
-        if constexpr (e != 0.0) acc = fma_(T(e), s.R[r][m], acc);
-      });
-      pn[r] = acc;
-    }
-  });
-  sfor<0, 3>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    s.R[r][ka] = fma_(g.c, Tm[r][ka], g.s * Tm[r][kb]);
-    s.R[r][kb] = fma_(g.c, Tm[r][kb], -(g.s * Tm[r][ka]));
-    s.R[r][k] = Tm[r][k];
-    s.p[r] = pn[r];
-  });
-  const T ang[3] = {s.R[0][k], s.R[1][k], s.R[2][k]};
-  T sl[3];
-  cross3(s.p, ang, sl);
-  sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; Sv[r] = ang[r]; Sv[3 + r] = sl[r]; });
-  if constexpr (root) {
-    sfor<0, 6>([&](auto R_) { Pd[decltype(R_)::value] = T(0); });
-    Pdd[0] = T(0); Pdd[1] = T(0); Pdd[2] = T(0);
-    Pdd[3] = grav * ang[1];
-    Pdd[4] = -(grav * ang[0]);
-    Pdd[5] = T(0);
-    sfor<0, 6>([&](auto R_) {
-      constexpr int r = decltype(R_)::value;
-      s.v[r] = Sv[r] * qd;
-      s.a[r] = Sv[r] * qdd;
-    });
-    s.a[5] -= grav;
-  } else {
-    T t1[6], t2[6];
-    crm6(s.v, Sv, Pd);
-    crm6(s.a, Sv, t1);
-    crm6(s.v, Pd, t2);
-    sfor<0, 6>([&](auto R_) {
-      constexpr int r = decltype(R_)::value;
-      Pdd[r] = t1[r] + t2[r];
-      s.v[r] = fma_(Sv[r], qd, s.v[r]);
-      s.a[r] = fma_(Sv[r], qdd, fma_(Pd[r], qd, s.a[r]));
-    });
-  }
-}
-
-// J -> parent(J): exact inverse of ws_down for a non-root body
-template <int J, class T>
-RBD_DEV void ws_up(WState<T>& s, const JTrig<T>& g, T qd, T qdd, const T (&Sv)[6], const T (&Pd)[6]) {
-  constexpr int k = AXIS[J], ka = (k + 1) % 3, kb = (k + 2) % 3;
-  sfor<0, 6>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    s.v[r] = fma_(-Sv[r], qd, s.v[r]);
-    s.a[r] = fma_(-Sv[r], qdd, fma_(-Pd[r], qd, s.a[r]));
-  });
-  T Tm[3][3];
-  sfor<0, 3>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    Tm[r][ka] = fma_(g.c, s.R[r][ka], -(g.s * s.R[r][kb]));
-    Tm[r][kb] = fma_(g.s, s.R[r][ka], g.c * s.R[r][kb]);
-    Tm[r][k] = s.R[r][k];
-  });
-  sfor<0, 3>([&](auto R_) {
-    sfor<0, 3>([&](auto C_) {
-      constexpr int r = decltype(R_)::value, c = decltype(C_)::value;
-      T acc = T(0);
-      sfor<0, 3>([&](auto M_) {
-        constexpr int m = decltype(M_)::value;
-        constexpr double e = Et_(J, m, c);
-        if constexpr (e == 1.0) acc = acc + Tm[r][m];
-        else if constexpr (e == -1.0) acc = acc - Tm[r][m];
-        else if constexpr (e != 0.0) acc = fma_(T(e), Tm[r][m], acc);
-      });
-      s.R[r][c] = acc;
-    });
-  });
-  sfor<0, 3>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    T acc = s.p[r];
-    sfor<0, 3>([&](auto M_) {
-      constexpr int m = decltype(M_)::value;
-      constexpr double e = rt_(J, m);
-      if constexpr (e != 0.0) acc = fma_(T(-e), s.R[r][m], acc);
-    });
-    s.p[r] = acc;
-  });
-}
-
-// composite of a subtree in the world frame: rigid inertia, Sym part of BC, momentum, force (:1436-1448)
-template <class T>
-struct Comp {
-  RInertia<T> IC;
-  SymB<T> SC;
-  T pm[6], f[6];
-};
-template <class T>
-RBD_DEV void comp_add(Comp<T>& a, const Comp<T>& b) {
-  a.IC.m += b.IC.m;
-  sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; a.IC.h[r] += b.IC.h[r]; a.SC.G[r] += b.SC.G[r]; });
-  sfor<0, 6>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    a.IC.I[r] += b.IC.I[r]; a.SC.TL[r] += b.SC.TL[r]; a.pm[r] += b.pm[r]; a.f[r] += b.f[r];
-  });
-}
-// body J's own terms from its world state
-template <int J, class T>
-RBD_DEV void comp_local(const WState<T>& s, Comp<T>& L) {
-  T cw[3];
-  sfor<0, 3>([&](auto R_) {
-    constexpr int r = decltype(R_)::value;
-    T acc = s.p[r];
-    sfor<0, 3>([&](auto M_) {
-      constexpr int m = decltype(M_)::value;
-      constexpr double e = com_(J, m);
-      if constexpr (e != 0.0) acc = fma_(T(e), s.R[r][m], acc);
-    });
-    cw[r] = acc;
-  });
-  L.IC.m = T(mass_(J));
-  sfor<0, 3>([&](auto R_) { L.IC.h[decltype(R_)::value] = T(mass_(J)) * cw[decltype(R_)::value]; });
-  {
-    T A[3][3];
-    sfor<0, 3>([&](auto R_) {
-      sfor<0, 3>([&](auto C_) {
-        constexpr int r = decltype(R_)::value, c = decltype(C_)::value;
-        T acc = T(0);
-        sfor<0, 3>([&](auto M_) {
-          constexpr int m = decltype(M_)::value;
-          constexpr double e = Ic_(J, m, c);
-          if constexpr (e != 0.0) acc = fma_(T(e), s.R[r][m], acc);
-        });
-        A[r][c] = acc;
-      });
-    });
-    const T cc = fma_(cw[0], cw[0], fma_(cw[1], cw[1], cw[2] * cw[2]));
-    constexpr int IR[6] = {0, 0, 0, 1, 1, 2}, IC_[6] = {0, 1, 2, 1, 2, 2};
-    sfor<0, 6>([&](auto E_) {
-      constexpr int e = decltype(E_)::value, r = IR[e], c = IC_[e];
-      T x = fma_(A[r][0], s.R[c][0], fma_(A[r][1], s.R[c][1], A[r][2] * s.R[c][2]));
-      const T mcc = L.IC.h[r] * cw[c];
-      if constexpr (r == c) x += fma_(L.IC.m, cc, -mcc); else x -= mcc;
-      L.IC.I[e] = x;
-    });
-  }
-  T Ia[6];
-  rin_apply(L.IC, s.v, L.pm);
-  rin_apply(L.IC, s.a, Ia);
-  fxv<false>(s.v, L.pm, L.f);
-  sfor<0, 6>([&](auto R_) { L.f[decltype(R_)::value] += Ia[decltype(R_)::value]; });
-  {
-    const T w[3] = {s.v[0], s.v[1], s.v[2]}, u[3] = {s.v[3], s.v[4], s.v[5]};
-    const T Ifull[3][3] = {{L.IC.I[0], L.IC.I[1], L.IC.I[2]}, {L.IC.I[1], L.IC.I[3], L.IC.I[4]}, {L.IC.I[2], L.IC.I[4], L.IC.I[5]}};
-    T K[3][3];
-    sfor<0, 3>([&](auto C_) {
-      constexpr int c = decltype(C_)::value;
-      const T col[3] = {Ifull[0][c], Ifull[1][c], Ifull[2][c]};
-      T o[3];
-      cross3(w, col, o);
-      K[0][c] = o[0]; K[1][c] = o[1]; K[2][c] = o[2];
-    });
-    const T uh2 = T(2) * fma_(u[0], L.IC.h[0], fma_(u[1], L.IC.h[1], u[2] * L.IC.h[2]));
-    constexpr int IR[6] = {0, 0, 0, 1, 1, 2}, IC_[6] = {0, 1, 2, 1, 2, 2};
-    sfor<0, 6>([&](auto E_) {
-      constexpr int e = decltype(E_)::value, r = IR[e], c = IC_[e];
-      T x = K[r][c] + K[c][r];
-      x = fma_(-L.IC.h[r], u[c], fma_(-u[r], L.IC.h[c], x));
-      if constexpr (r == c) x += uh2;
-      L.SC.TL[e] = x;
-    });
-    T g[3];
-    cross3(w, L.IC.h, g);
-    sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; L.SC.G[r] = fma_(L.IC.m, u[r], g[r]); });
-  }
-}
-// flat view of a composite (31 scalars) for parking
-template <class T, class F>
-RBD_DEV void comp_each(Comp<T>& c, F&& f) {
-  f(std::integral_constant<int, 0>{}, c.IC.m);
-  sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; f(std::integral_constant<int, 1 + r>{}, c.IC.h[r]); });
-  sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; f(std::integral_constant<int, 4 + r>{}, c.IC.I[r]); });
-  sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; f(std::integral_constant<int, 10 + r>{}, c.SC.TL[r]); });
-  sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; f(std::integral_constant<int, 16 + r>{}, c.SC.G[r]); });
-  sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; f(std::integral_constant<int, 19 + r>{}, c.pm[r]); });
-  sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; f(std::integral_constant<int, 25 + r>{}, c.f[r]); });
-}
 
 template <class T, bool HAS_QDD>
 __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T* __restrict__ q, const T* __restrict__ qd,

@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
 
 }  // namespace rbdk
 #include "rbd_idsva.h"
+#include "rbd_idsva_pipe.h"
 #include "rbd_idsva_tree.h"
 #ifdef RBD_NEED_GRAD
 #include "rbd_grad_cols.h"
@@ -2138,6 +2139,20 @@ int idsva_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_dampi
   const size_t lds = sizeof(T) * (size_t)64 * IDS_TS;
   if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
   int rc, resident = 0;
+#ifndef RBD_EXP_NO_PIPE
+  // one chain, fp32, plain rnea_grad: the software-pipelined tile loop (rbd_idsva_pipe.h)
+  if constexpr (!FDG && IDS_PIPE_OK && sizeof(T) == 4) {
+    auto kp = rnea_grad_idsva_pipe_kernel<T, HAS_QDD>;
+    if ((rc = ensure_lds(kp, lds)) != 0) return rc;
+    if ((rc = resident_blocks(kp, 64, lds, &resident)) != 0) return rc;
+    const int64_t blocks = tiles < resident ? tiles : resident;
+    hipLaunchKernelGGL(kp, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping,
+                       (long long)B, c, dc_du);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
+    return 0;
+  }
+#endif
   auto k = rnea_grad_idsva_kernel<T, HAS_QDD, FDG>;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;
   if ((rc = resident_blocks(k, 64, lds, &resident)) != 0) return rc;
@@ -2265,7 +2280,13 @@ int grad_kernel_name(int64_t B, char* buf, size_t len) {
   bool tree = TREE_ONLY;
   if constexpr (TREE_BUILT) tree = tree || (rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE && tree_lds_bytes<T>() <= 160 * 1024);
   if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);
-  else if (grad_chain_kernel<T>()) std::snprintf(buf, len, "rnea_grad_idsva_kernel<%s,true,false>", t);
+  else if (grad_chain_kernel<T>()) {
+#ifndef RBD_EXP_NO_PIPE
+    if (IDS_PIPE_OK && sizeof(T) == 4) std::snprintf(buf, len, "rnea_grad_idsva_pipe_kernel<%s,true>", t);
+    else
+#endif
+    std::snprintf(buf, len, "rnea_grad_idsva_kernel<%s,true,false>", t);
+  }
   else std::snprintf(buf, len, "rnea_grad_kernel<%s,true,false>", t);
   return 0;
 }
@@ -2294,11 +2315,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
     if (e != hipSuccess) return hip_fail(e, "rbd_minv launch");
     return 0;
   } else {
-  const size_t need = (size_t)B * MINV_WS_PER_CFG * sizeof(T);
-  if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
-  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  T* ws = reinterpret_cast<T*>(workspace);
   const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
   // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
   // otherwise eight lanes per configuration (rbd_minv_ia8.h), which also finishes the groups of <= 8 bodies
@@ -2318,6 +2335,12 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
       return 0;
     }
   }
+  // the two-launch path is the only one that goes through the HBM workspace (rbd_minv_workspace_bytes reports 0
+  // when the one-launch kernel is selected)
+  const size_t need = (size_t)B * MINV_WS_PER_CFG * sizeof(T);
+  if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
+  T* ws = reinterpret_cast<T*>(workspace);
   const bool lane_a = pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4);
   const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B, !lane_a);
   if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
@@ -2357,6 +2380,17 @@ int minv_kernel_name(int64_t B, char* buf, size_t len) {
   else if (fused) std::snprintf(buf, len, "minv_fused_kernel<%s>", t);
   else std::snprintf(buf, len, "minv_cols_kernel<%s>", t);
   return 0;
+}
+
+// does minv_launch<T> go through the HBM workspace under the current options?
+template <class T>
+int minv_needs_workspace() {
+  if constexpr (rbdk::MINV_USE_LANE) return 0;
+  if constexpr (rbdk::MINV_FUSED_OK && rbdk::mf_lds_bytes<T>() <= 160 * 1024) {
+    const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
+    if (pa == RBD_MINV_PHASE_A_FUSED || pa == RBD_MINV_PHASE_A_AUTO) return 0;
+  }
+  return 1;
 }
 
 #endif  // RBD_NEED_MINV
@@ -2543,6 +2577,8 @@ __attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f32(int64_t B, ch
 __attribute__((visibility("hidden"))) int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len);
+__attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f32(void);
+__attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f64(void);
 __attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f32(int64_t B, char* buf, size_t len);
 __attribute__((visibility("hidden"))) int rbd_rnea_kernel_name_f64(int64_t B, char* buf, size_t len);
 #ifdef RBD_TU_RNEA_F32
@@ -2559,9 +2595,11 @@ int rbd_grad_kernel_name_f64(int64_t B, char* buf, size_t len) { return grad_ker
 #endif
 #ifdef RBD_TU_MINV_F32
 int rbd_minv_kernel_name_f32(int64_t B, char* buf, size_t len) { return minv_kernel_name<float>(B, buf, len); }
+int rbd_minv_needs_ws_f32(void) { return minv_needs_workspace<float>(); }
 #endif
 #ifdef RBD_TU_MINV_F64
 int rbd_minv_kernel_name_f64(int64_t B, char* buf, size_t len) { return minv_kernel_name<double>(B, buf, len); }
+int rbd_minv_needs_ws_f64(void) { return minv_needs_workspace<double>(); }
 #endif
 
 #ifdef RBD_TU_COMMON
@@ -2614,6 +2652,9 @@ int rbd_model_info(rbd_model_info_t* out) {
 size_t rbd_minv_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0 || (elem_size != 4 && elem_size != 8)) return 0;
   if (rbdm::FLOATING_BASE) return 0;
+  // none when the kernel selected by the current RBD_OPT_MINV_PHASE_A runs without it (the one-lane kernel, the
+  // one-launch kernel): query again after changing that option
+  if (!(elem_size == 4 ? rbd_minv_needs_ws_f32() : rbd_minv_needs_ws_f64())) return 0;
   return (size_t)B * rbdk::MINV_WS_PER_CFG * (size_t)elem_size;
 }
 size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {

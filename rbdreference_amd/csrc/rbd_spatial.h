@@ -266,8 +266,10 @@ RBD_DEV T dot6(const T (&x)[6], const T (&y)[6]) {
 // classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]: max abs error 9.2e-8 over the range (numpy
 // emulation, 6 M samples; a correctly rounded result has 3e-8), ~22 instructions against ~45 for sincosf, which
 // carries the Payne-Hanek path for huge arguments.  Larger |q| take sincosf (a branch no lane takes in practice).
-RBD_DEV void sincos_(float q, float* s, float* c) {
-  if (__builtin_expect(__builtin_fabsf(q) > 8192.0f, 0)) { sincosf(q, s, c); return; }
+// The quadrant fix-up is bit arithmetic (v_bfe_i32 / v_bfi_b32 / shift / and / xor), not compares and selects: measured
+// (tools/ubench/pk_issue.hip) a v_cndmask_b32 costs a wave 6.4 cycles in its VOP3 form and 16.7 in the VOP2 form that
+// reads VCC, a v_cmp 9, against 5.2-5.7 for a plain VOP2 instruction -- and the selects of two waves do not overlap.
+RBD_DEV void sincos_core_(float q, float* s, float* c) {                      // |q| <= 8192
   const float kf = __builtin_rintf(q * 0.63661977236758134f);                 // q * 2 / pi
   float r = __builtin_fmaf(-kf, 1.5707963705062866f, q);                      // pi/2 = hi + mid (+ 1.8e-15)
   r = __builtin_fmaf(-kf, -4.371138828673793e-08f, r);
@@ -279,10 +281,18 @@ RBD_DEV void sincos_(float q, float* s, float* c) {
   float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
   cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
   cp = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
-  const bool swap = (k & 1) != 0;
-  const float ss = swap ? cp : sp, cc = swap ? sp : cp;
-  *s = (k & 2) ? -ss : ss;
-  *c = ((k + 1) & 2) ? -cc : cc;
+  const unsigned us = __builtin_bit_cast(unsigned, sp), uc = __builtin_bit_cast(unsigned, cp);
+  const unsigned m = (unsigned)-(k & 1);                                      // all ones when k is odd: sin and cos trade places
+  unsigned ss = (uc & m) | (us & ~m);
+  unsigned cc = (us & m) | (uc & ~m);
+  ss ^= ((unsigned)k << 30) & 0x80000000u;                                    // sin changes sign in quadrants 2, 3
+  cc ^= ((unsigned)(k + 1) << 30) & 0x80000000u;                              // cos in quadrants 1, 2
+  *s = __builtin_bit_cast(float, ss);
+  *c = __builtin_bit_cast(float, cc);
+}
+RBD_DEV void sincos_(float q, float* s, float* c) {
+  if (__builtin_expect(__builtin_fabsf(q) > 8192.0f, 0)) { sincosf(q, s, c); return; }
+  sincos_core_(q, s, c);
 }
 RBD_DEV void sincos_(double q, double* s, double* c) { sincos(q, s, c); }
 

@@ -116,6 +116,7 @@ def pack_robot(robot, name: str | None = None) -> PackedModel:
             Xt[0] = np.eye(6)
             I = np.asarray(robot.get_Imat_by_id(0), dtype=np.float64).reshape(6, 6)
             Im[0] = 0.5 * (I + I.T)
+            damp[0] = float(robot.get_damping_by_id(0))     # the base's 5x5 damping block (:1336-1339)
             continue
         for g in ("get_joint_index_q", "get_joint_index_v", "get_joint_index_f"):
             if int(getattr(robot, g)(i)) != i + off:
