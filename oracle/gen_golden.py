@@ -134,10 +134,26 @@ def run_reference_fb(robot, q, qd, qdd):
             out.setdefault("dc_du", []).append(ref.rnea_grad(qs, qds, qdds).copy())
             out.setdefault("dc_du_noqdd", []).append(ref.rnea_grad(qs, qds).copy())
             out.setdefault("dc_du_damped", []).append(ref.rnea_grad(qs, qds, qdds, USE_VELOCITY_DAMPING=True).copy())
+            # the four gradient passes (README.md:19) and forward_dynamics_grad, which the reference also runs here
+            c2, v2, a2, f2 = ref.rnea(qs, qds, qdds)
+            dv, da, df = ref.rnea_grad_fpass_dq(qs, qds, v2, a2)
+            out.setdefault("dq_dv", []).append(dv.copy()); out.setdefault("dq_da", []).append(da.copy()); out.setdefault("dq_df", []).append(df.copy())
+            dv2, da2, df2 = ref.rnea_grad_fpass_dqd(qs, qds, v2)
+            out.setdefault("dqd_dv", []).append(dv2.copy()); out.setdefault("dqd_da", []).append(da2.copy()); out.setdefault("dqd_df", []).append(df2.copy())
+            dfm = df.copy()
+            out.setdefault("dc_dq", []).append(ref.rnea_grad_bpass_dq(qs, f2, dfm).copy())
+            out.setdefault("dq_df_after", []).append(dfm.copy())                  # the pass mutates df (:1291-1294)
+            dfm2 = df2.copy()
+            out.setdefault("dc_dqd", []).append(ref.rnea_grad_bpass_dqd(qs, dfm2).copy())
+            out.setdefault("dqd_df_after", []).append(dfm2.copy())
+            out.setdefault("dc_dqd_damped", []).append(ref.rnea_grad_bpass_dqd(qs, df2.copy(), True).copy())
+            a1, a2_ = ref.forward_dynamics_grad(qs, qds, qdds)
+            out.setdefault("fd_dq", []).append(np.asarray(a1).copy()); out.setdefault("fd_dqd", []).append(np.asarray(a2_).copy())
     data = {k: np.stack(vv) for k, vv in out.items()}
     raises = []
     for nm, fn in (("rnea_grad", lambda: ref.rnea_grad(q[0], qd[0], qdd[0])), ("crba", lambda: ref.crba(q[0])),
-                   ("aba", lambda: ref.aba(q[0], qd[0], qdd[0]))):
+                   ("aba", lambda: ref.aba(q[0], qd[0], qdd[0])),
+                   ("forward_dynamics_grad", lambda: ref.forward_dynamics_grad(q[0], qd[0], qdd[0]))):
         try:
             fn()
             raises.append(f"{nm}: ran")

@@ -22,7 +22,9 @@ import numpy as np
 from . import rbd_oracle as fx
 
 __all__ = ["FbModel", "model_from_robot", "Xmats", "rnea_fpass", "rnea_bpass", "rnea", "minv_bpass",
-           "minv_fpass", "minv", "forward_dynamics", "joint_space_inertia", "rnea_grad"]
+           "minv_fpass", "minv", "forward_dynamics", "joint_space_inertia", "rnea_grad",
+           "rnea_grad_fpass_dq", "rnea_grad_fpass_dqd", "rnea_grad_bpass_dq", "rnea_grad_bpass_dqd",
+           "forward_dynamics_grad"]
 
 
 @dataclass
@@ -303,3 +305,140 @@ def rnea_grad(m: FbModel, q, qd, qdd=None, GRAVITY=-9.81, USE_VELOCITY_DAMPING=F
             else:
                 dc[:, ind, n + ind] += m.damping[ind]
     return dc[0] if unb else dc
+
+
+# ---- the four gradient passes as the reference exposes them (README.md:19: the accelerator-testing surface) ----
+# Layouts follow the reference: dv / da / df are (6, n, NB) per configuration -> [B, 6, n, NB] here; the backward
+# passes mutate df in place (:1291, :1331): the mutated copy is returned next to dc.
+
+def _cols_of(i):
+    return list(range(6)) if i == 0 else [i + 5]
+
+
+def rnea_grad_fpass_dq(m: FbModel, q, qd, v, a, GRAVITY=-9.81):
+    """RBDReference.py:1127-1187 with the floating-base branches (:1141-1147, :1165-1169, :1173-1175).  NB >= 6 only
+    (the reference indexes bodies 0..5 at :1168); those updates add zeros (dv_dq of the base is zero)."""
+    assert m.nb >= 6
+    q, unb = _batch(q, m.n); qd, _ = _batch(qd, m.n)
+    v = np.asarray(v, dtype=np.float64); a = np.asarray(a, dtype=np.float64)
+    if unb:
+        v, a = v[None], a[None]
+    B = q.shape[0]; n = m.n; nb = m.nb
+    X = Xmats(m, q)
+    g = np.zeros(6); g[5] = -GRAVITY
+    crm = fx._crm
+    dv = np.zeros((B, 6, n, nb)); da = np.zeros((B, 6, n, nb)); df = np.zeros((B, 6, n, nb))
+    for i in range(nb):
+        p = m.parent[i]
+        if p != -1:
+            idx = i + 5
+            Xi = X[:, i]
+            dv[:, :, :, i] = np.einsum("bij,bjc->bic", Xi, dv[:, :, :, p])                                  # :1158
+            dv[:, :, idx, i] += np.einsum("bij,j->bi", crm(np.einsum("bij,bj->bi", Xi, v[:, :, p])), m.S[i])   # :1159
+            da[:, :, :, i] = np.einsum("bij,bjc->bic", Xi, da[:, :, :, p])                                  # :1163
+            da[:, :, :, i] += qd[:, idx][:, None, None] * np.einsum("bcij,j->bic", crm(np.moveaxis(dv[:, :, :, i], 1, 2)), m.S[i])   # :1170
+            da[:, :, idx, i] += np.einsum("bij,j->bi", crm(np.einsum("bij,bj->bi", Xi, a[:, :, p])), m.S[i])   # :1173
+        else:
+            # :1165-1168 add crm(dv) S[ii] qd[ii] with dv = 0 -> nothing;  :1175: da[:, idx, 0] += crm(X a_grav) S
+            da[:, :, 0:6, 0] += crm(X[:, 0] @ g)
+        Iv = np.einsum("ij,bj->bi", m.I[i], v[:, :, i])
+        df[:, :, :, i] = np.einsum("ij,bjc->bic", m.I[i], da[:, :, :, i])                                   # :1180
+        dvi = np.moveaxis(dv[:, :, :, i], 1, 2)                                                             # [B, n, 6]
+        df[:, :, :, i] += np.moveaxis(fx._fxv(dvi.reshape(B * n, 6), np.repeat(Iv, n, axis=0)).reshape(B, n, 6), 1, 2)   # :1184
+        Idv = np.einsum("ij,bcj->bci", m.I[i], dvi)
+        df[:, :, :, i] += np.moveaxis(fx._fxv(np.repeat(v[:, :, i], n, axis=0), Idv.reshape(B * n, 6)).reshape(B, n, 6), 1, 2)   # :1185
+    return (dv[0], da[0], df[0]) if unb else (dv, da, df)
+
+
+def rnea_grad_fpass_dqd(m: FbModel, q, qd, v):
+    """RBDReference.py:1189-1255 with the floating-base branches (:1212-1218, :1231, :1235-1243)."""
+    q, unb = _batch(q, m.n); qd, _ = _batch(qd, m.n)
+    v = np.asarray(v, dtype=np.float64)
+    if unb:
+        v = v[None]
+    B = q.shape[0]; n = m.n; nb = m.nb
+    X = Xmats(m, q)
+    crm = fx._crm
+    dv = np.zeros((B, 6, n, nb)); da = np.zeros((B, 6, n, nb)); df = np.zeros((B, 6, n, nb))
+    for i in range(nb):
+        p = m.parent[i]
+        if p != -1:
+            idx = i + 5
+            Xi = X[:, i]
+            dv[:, :, :, i] = np.einsum("bij,bjc->bic", Xi, dv[:, :, :, p])                                  # :1230
+            dv[:, :, idx, i] += m.S[i]                                                                      # :1231
+            da[:, :, :, i] = np.einsum("bij,bjc->bic", Xi, da[:, :, :, p])                                  # :1234
+            da[:, :, :, i] += qd[:, idx][:, None, None] * np.einsum("bcij,j->bic", crm(np.moveaxis(dv[:, :, :, i], 1, 2)), m.S[i])   # :1240
+            da[:, :, idx, i] += np.einsum("bij,j->bi", crm(v[:, :, i]), m.S[i])                              # :1243
+        else:
+            dv[:, :, 0:6, 0] += np.eye(6)                                                                   # :1231 with S = eye(6)
+            # :1236-1238: sum_ii qd_ii crm(dv[:, c]) S[ii] = crm(dv[:, c]) qd[0:6]
+            da[:, :, :, 0] += np.einsum("bcij,bj->bic", crm(np.moveaxis(dv[:, :, :, 0], 1, 2)), qd[:, 0:6])
+            da[:, :, 0:6, 0] += crm(v[:, :, 0])                                                             # :1243  crm(v) S
+        Iv = np.einsum("ij,bj->bi", m.I[i], v[:, :, i])
+        df[:, :, :, i] = np.einsum("ij,bjc->bic", m.I[i], da[:, :, :, i])                                   # :1247
+        dvi = np.moveaxis(dv[:, :, :, i], 1, 2)
+        df[:, :, :, i] += np.moveaxis(fx._fxv(dvi.reshape(B * n, 6), np.repeat(Iv, n, axis=0)).reshape(B, n, 6), 1, 2)   # :1251
+        Idv = np.einsum("ij,bcj->bci", m.I[i], dvi)
+        df[:, :, :, i] += np.moveaxis(fx._fxv(np.repeat(v[:, :, i], n, axis=0), Idv.reshape(B * n, 6)).reshape(B, n, 6), 1, 2)   # :1252
+    return (dv[0], da[0], df[0]) if unb else (dv, da, df)
+
+
+def rnea_grad_bpass_dq(m: FbModel, q, f, df_dq):
+    """RBDReference.py:1257-1297: dc_dq[0:6] = df[:, :, 0] (:1282), dc_dq[i + 5] = S^T df[:, :, i]; X^T df and the
+    fxS term go to the parent IN PLACE.  Returns (dc_dq, df_dq after the pass)."""
+    q, unb = _batch(q, m.n)
+    f = np.asarray(f, dtype=np.float64)
+    df = np.array(df_dq, dtype=np.float64, copy=True)
+    if unb:
+        f, df = f[None], df[None]
+    B = q.shape[0]; n = m.n
+    X = Xmats(m, q)
+    dc = np.zeros((B, n, n))
+    for i in range(m.nb - 1, -1, -1):
+        p = m.parent[i]
+        if p == -1:
+            dc[:, 0:6, :] = df[:, :, :, 0]
+        else:
+            idx = i + 5
+            dc[:, idx, :] = np.einsum("j,bjc->bc", m.S[i], df[:, :, :, i])
+            df[:, :, :, p] += np.einsum("bji,bjc->bic", X[:, i], df[:, :, :, i])                            # :1291
+            fxS = -np.einsum("bij,j->bi", fx._crm(f[:, :, i]), m.S[i])                                      # :166-168
+            df[:, :, idx, p] += np.einsum("bji,bj->bi", X[:, i], fxS)                                       # :1292-1294
+    return (dc[0], df[0]) if unb else (dc, df)
+
+
+def rnea_grad_bpass_dqd(m: FbModel, q, df_dqd, USE_VELOCITY_DAMPING=False):
+    """RBDReference.py:1299-1343; the damping lines (:1336-1341) literally: matrix index = BODY id, a 5 x 5 block for
+    the base.  Returns (dc_dqd, df_dqd after the pass)."""
+    q, unb = _batch(q, m.n)
+    df = np.array(df_dqd, dtype=np.float64, copy=True)
+    if unb:
+        df = df[None]
+    B = q.shape[0]; n = m.n
+    X = Xmats(m, q)
+    dc = np.zeros((B, n, n))
+    for i in range(m.nb - 1, -1, -1):
+        p = m.parent[i]
+        if p == -1:
+            dc[:, 0:6, :] = df[:, :, :, 0]                                                                  # :1325 with S = eye(6)
+        else:
+            dc[:, i + 5, :] = np.einsum("j,bjc->bc", m.S[i], df[:, :, :, i])
+            df[:, :, :, p] += np.einsum("bji,bjc->bic", X[:, i], df[:, :, :, i])                            # :1331
+    if USE_VELOCITY_DAMPING:
+        for ind in range(m.nb):
+            if m.parent[ind] == -1:
+                dc[:, ind:ind + 5, ind:ind + 5] += m.damping[ind]
+            else:
+                dc[:, ind, ind] += m.damping[ind]
+    return (dc[0], df[0]) if unb else (dc, df)
+
+
+def forward_dynamics_grad(m: FbModel, q, qd, u, GRAVITY=-9.81):
+    """RBDReference.py:1376-1384: qdd = forward_dynamics; [qdd_dq | qdd_dqd] = -Minv dc_du(q, qd, qdd)."""
+    q2, unb = _batch(q, m.n)
+    qdd = forward_dynamics(m, q, qd, u, GRAVITY)
+    dc = rnea_grad(m, q, qd, qdd, GRAVITY)
+    Mi = minv(m, q)
+    d = -np.einsum("...ij,...jk->...ik", Mi, dc)
+    return d[..., :, :m.n], d[..., :, m.n:]

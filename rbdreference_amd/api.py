@@ -164,7 +164,7 @@ class RBDReference:
             fc = torch.as_tensor(fa, device=dev).contiguous()
             ft = None
         with torch.cuda.device(dev):
-            c = torch.empty((B, self.n), device=dev, dtype=dt)
+            c = torch.empty((B, self.nv), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
             self._lib.check(self._fn("rbd_rnea_bpass", dt)(self._ptr(q), self._ptr(fc), B, self._ptr(c), st))
         if ft is not None and fc is not ft:
@@ -212,10 +212,11 @@ class RBDReference:
         df_dq)``, each ``(6, n, NB)`` per configuration; ``v, a`` are rnea's outputs."""
         (q, qd), unb, is_np, dev, dt = self._prep(q, qd)
         B, n = q.shape
-        v, _ = self._aux(v, (B, 6, n), unb, is_np, dev, dt, "v")
-        a, _ = self._aux(a, (B, 6, n), unb, is_np, dev, dt, "a")
+        nb = self.n                        # bodies (== n unless the base floats: n = NB + 5)
+        v, _ = self._aux(v, (B, 6, nb), unb, is_np, dev, dt, "v")
+        a, _ = self._aux(a, (B, 6, nb), unb, is_np, dev, dt, "a")
         with torch.cuda.device(dev):
-            dv = torch.empty((B, 6, n, n), device=dev, dtype=dt)
+            dv = torch.empty((B, 6, n, nb), device=dev, dtype=dt)
             da = torch.empty_like(dv)
             df = torch.empty_like(dv)
             st = torch.cuda.current_stream(dev).cuda_stream
@@ -229,9 +230,10 @@ class RBDReference:
         df_dqd)``, each ``(6, n, NB)`` per configuration."""
         (q, qd), unb, is_np, dev, dt = self._prep(q, qd)
         B, n = q.shape
-        v, _ = self._aux(v, (B, 6, n), unb, is_np, dev, dt, "v")
+        nb = self.n
+        v, _ = self._aux(v, (B, 6, nb), unb, is_np, dev, dt, "v")
         with torch.cuda.device(dev):
-            dv = torch.empty((B, 6, n, n), device=dev, dtype=dt)
+            dv = torch.empty((B, 6, n, nb), device=dev, dtype=dt)
             da = torch.empty_like(dv)
             df = torch.empty_like(dv)
             st = torch.cuda.current_stream(dev).cuda_stream
@@ -245,8 +247,8 @@ class RBDReference:
         reference's argument (``:1291-1294``)."""
         (q,), unb, is_np, dev, dt = self._prep(q)
         B, n = q.shape
-        f, _ = self._aux(f, (B, 6, n), unb, is_np, dev, dt, "f")
-        df, origin = self._aux(df_dq, (B, 6, n, n), unb, is_np, dev, dt, "df_dq")
+        f, _ = self._aux(f, (B, 6, self.n), unb, is_np, dev, dt, "f")
+        df, origin = self._aux(df_dq, (B, 6, n, self.n), unb, is_np, dev, dt, "df_dq")
         with torch.cuda.device(dev):
             dc = torch.empty((B, n, n), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
@@ -260,7 +262,7 @@ class RBDReference:
         ``df_dqd`` accumulated in place (``:1331``)."""
         (q,), unb, is_np, dev, dt = self._prep(q)
         B, n = q.shape
-        df, origin = self._aux(df_dqd, (B, 6, n, n), unb, is_np, dev, dt, "df_dqd")
+        df, origin = self._aux(df_dqd, (B, 6, n, self.n), unb, is_np, dev, dt, "df_dqd")
         with torch.cuda.device(dev):
             dc = torch.empty((B, n, n), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
@@ -426,7 +428,7 @@ class RBDReference:
                 return qdd, None, unb, is_np
             wsb = int(self._lib.lib.rbd_fd_workspace_bytes(B, esz))
             ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
-            d = torch.empty((B, self.n, 2 * self.n), device=dev, dtype=dt)
+            d = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
             self._lib.check(self._fn("rbd_forward_dynamics_grad", dt)(
                 self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
                 self._ptr(d), ws.data_ptr(), wsb, st))
@@ -442,6 +444,6 @@ class RBDReference:
         """RBDReference.forward_dynamics_grad (``RBDReference.py:1376-1384``) -> ``(qdd_dq, qdd_dqd)``,
         each ``(n, n)`` per configuration (views of one ``[B, n, 2n]`` buffer for tensor inputs)."""
         _, d, unb, is_np = self._fd(q, qd, u, GRAVITY, True)
-        n = self.n
+        n = self.nv
         d = self._ret(d, unb, is_np)
         return d[..., :n], d[..., n:]

@@ -146,14 +146,23 @@ RBD_DEV void fb_inv6(const T (&A)[6][6], T (&Ai)[6][6]) {
 // FB_MINV_L lanes per configuration: every lane runs the articulated-inertia recursion of its configuration
 // (redundantly: about as much work as three joint columns) and takes the joint columns jb = 1 + sub, 1 + sub + L, ...
 // -- 4x the waves and 2x less work per lane than one lane per configuration (fp32 B = 65 536: 214 -> 80 us; 88 us with 8).
+// The block's matrices ([16][nv * nv]) are assembled in LDS and leave as flat 16-byte copies of whole lines (the first
+// version stored every entry on its own: 4-byte stores 72 bytes apart).
 constexpr int FB_MINV_L = 4;
+constexpr int FB_MINV_C = 64 / FB_MINV_L;    // configurations per block
+template <class T>
+constexpr size_t minv_fb_lds_bytes() { return sizeof(T) * (size_t)FB_MINV_C * NV * NV; }
 template <class T>
 __global__ __launch_bounds__(64, 1) void minv_fb_kernel(const T* __restrict__ q, long long B, int dense, T* __restrict__ Minv) {
-  const int sub = threadIdx.x % FB_MINV_L;
-  const long long b = (long long)blockIdx.x * (64 / FB_MINV_L) + threadIdx.x / FB_MINV_L;
-  if (b >= B) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* img = reinterpret_cast<T*>(smem_raw);
+  const int sub = threadIdx.x % FB_MINV_L, slot = threadIdx.x / FB_MINV_L;
+  const long long cfg0 = (long long)blockIdx.x * FB_MINV_C;
+  const long long rem = B - cfg0;
+  const int nvalid = rem < FB_MINV_C ? (int)rem : FB_MINV_C;
+  const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);   // lanes beyond the batch repeat its last configuration (their image slot is never flushed)
   const T* qb = q + b * NV;
-  T* Mb = Minv + b * (NV * NV);
+  T* Mb = img + slot * (NV * NV);
   JTrig<T> tr[N];
   sfor<1, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qb[j + 5]); });
   // ---- articulated inertias, U = IA S, D = S^T U (:662, :697-700, :728-733) -------------------------
@@ -255,6 +264,22 @@ __global__ __launch_bounds__(64, 1) void minv_fb_kernel(const T* __restrict__ q,
         if (i < jb) Mb[j * NV + i + 5] = dense ? mcol[i] : T(0);
       }
     });
+  }
+  // ---- the image leaves: [nvalid][nv * nv] is contiguous in Minv ------------------------------------------
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {
+    constexpr int VE = 16 / sizeof(T);
+    T* gdst = Minv + cfg0 * (NV * NV);
+    const int lane = threadIdx.x;
+    if (nvalid == FB_MINV_C && (FB_MINV_C * NV * NV) % VE == 0) {
+      typedef T V __attribute__((ext_vector_type(VE)));
+      constexpr int NVEC = FB_MINV_C * NV * NV / VE;
+#pragma unroll 4
+      for (int g = lane; g < NVEC; g += 64) reinterpret_cast<V*>(gdst)[g] = reinterpret_cast<const V*>(img)[g];
+    } else {
+      for (int g = lane; g < nvalid * NV * NV; g += 64) gdst[g] = img[g];
+    }
   }
 }
 

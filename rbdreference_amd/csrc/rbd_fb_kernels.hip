@@ -8,6 +8,7 @@
 // Units: -DRBD_TU_FB_F32 / -DRBD_TU_FB_F64 (rbdreference_amd/build.py).
 #include "rbd_fb.h"
 #include "rbd_fb_world.h"
+#include "rbd_fb_passes.h"
 #include "../../include/rbd_hip.h"
 #include <cstdio>
 #include <cstring>
@@ -26,8 +27,8 @@ int hip_fail(hipError_t e, const char* where) {
 }
 int unsupported(const char* who) {
   std::snprintf(rbd_err_buf(), RBD_ERR_LEN,
-                "%s: not available for floating-base robots (supported: rbd_rnea, rbd_rnea_grad, rbd_rnea_with_grad, "
-                "rbd_minv, rbd_forward_dynamics)", who);
+                "%s: not available for floating-base robots (the reference's own crba / aba raise for them, "
+                "RBDReference.py:1063, :900)", who);
   return RBD_ERR_UNSUPPORTED;
 }
 constexpr size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -141,7 +142,12 @@ int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
   if (misaligned(Minv)) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be 16-byte aligned");
   const int64_t blocks = (B + 64 / FB_MINV_L - 1) / (64 / FB_MINV_L);
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
-  hipLaunchKernelGGL((minv_fb_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, dense, Minv);
+  constexpr size_t lds = minv_fb_lds_bytes<T>();
+  if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_minv: the block's matrices do not fit LDS for this robot size");
+  auto k = minv_fb_kernel<T>;
+  int rc;
+  if ((rc = ensure_lds(k, lds)) != 0) return rc;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, (long long)B, dense, Minv);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_minv (floating base) launch");
 }
@@ -166,6 +172,139 @@ int fd_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* q
   hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_forward_dynamics (floating base) launch");
+}
+// ---- per-pass surface (README.md:19) ---------------------------------------------------------------------------
+template <class T>
+int rnea_pass_fb_launch(int mode, const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {
+  using namespace rbdk;
+  const char* who = mode == 1 ? "rbd_rnea_fpass" : "rbd_rnea_bpass";
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea pass: B < 0");
+  if (B == 0) return 0;
+  if (mode == 1 && (!q || !qd || !v || !a || !f)) return fail(RBD_ERR_ARG, "rbd_rnea_fpass: q, qd, v, a, f must be non-null");
+  if (mode == 2 && (!q || !f || !c)) return fail(RBD_ERR_ARG, "rbd_rnea_bpass: q, f, c must be non-null");
+  if (misaligned(c) || misaligned(v) || misaligned(a) || misaligned(f)) return fail(RBD_ERR_ARG, "rbd_rnea pass: output buffers must be 16-byte aligned");
+  const int64_t blocks = (B + 63) / 64;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea pass: B too large");
+  constexpr size_t lds = rnea_fbw_lds_bytes<T>();
+  if constexpr (lds > 160 * 1024) {
+    std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: the [64][6 NB] image does not fit LDS for this robot size", who);
+    return RBD_ERR_UNSUPPORTED;
+  } else {
+    int rc;
+    if (mode == 2) {
+      auto k = rnea_fbw_kernel<T, false, 2>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, (const T*)nullptr, (const T*)nullptr, gravity, (long long)B, c, (T*)nullptr, (T*)nullptr, f);
+    } else if (qdd) {
+      auto k = rnea_fbw_kernel<T, true, 1>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, (T*)nullptr, v, a, f);
+    } else {
+      auto k = rnea_fbw_kernel<T, false, 1>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, (long long)B, (T*)nullptr, v, a, f);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, who);
+  }
+}
+int grad_pass_needs_six(const char* who) {
+  std::snprintf(rbd_err_buf(), RBD_ERR_LEN, "%s: floating-base gradient passes need NB >= 6 (the reference raises IndexError below, "
+                "RBDReference.py:1168); this robot has NB = %d", who, rbdk::N);
+  return RBD_ERR_UNSUPPORTED;
+}
+template <class T, bool ISQD>
+int grad_fpass_fb_launch(const T* q, const T* qd, const T* v, const T* a, T gravity, int64_t B, T* dv, T* da, T* df, void* stream) {
+  using namespace rbdk;
+  const char* who = ISQD ? "rbd_rnea_grad_fpass_dqd" : "rbd_rnea_grad_fpass_dq";
+  if constexpr (N < 6) return grad_pass_needs_six(who);
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad_fpass: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !v || (!ISQD && !a) || !dv || !da || !df) return fail(RBD_ERR_ARG, "rbd_rnea_grad_fpass: null argument");
+  const int64_t blocks = (B + FBP_C - 1) / FBP_C;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad_fpass: B too large");
+  hipLaunchKernelGGL((fb_grad_fpass_kernel<T, ISQD>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, qd, v, a, gravity, (long long)B, dv, da, df);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, who);
+}
+template <class T, bool ISQD>
+int grad_bpass_fb_launch(const T* q, const T* f, T* df, int use_damping, int64_t B, T* dc, void* stream) {
+  using namespace rbdk;
+  const char* who = ISQD ? "rbd_rnea_grad_bpass_dqd" : "rbd_rnea_grad_bpass_dq";
+  if constexpr (N < 6) return grad_pass_needs_six(who);
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad_bpass: B < 0");
+  if (B == 0) return 0;
+  if (!q || (!ISQD && !f) || !df || !dc) return fail(RBD_ERR_ARG, "rbd_rnea_grad_bpass: null argument");
+  const int64_t blocks = (B + FBP_C - 1) / FBP_C;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad_bpass: B too large");
+  hipLaunchKernelGGL((fb_grad_bpass_kernel<T, ISQD>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, f, df, use_damping, (long long)B, dc);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, who);
+}
+template <class T>
+int minv_bpass_fb_launch(const T* q, int64_t B, T* Minv, T* F, T* U, T* Dinv, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv_bpass: B < 0");
+  if (B == 0) return 0;
+  if (!q || !Minv || !F || !U || !Dinv) return fail(RBD_ERR_ARG, "rbd_minv_bpass: null argument");
+  const int64_t blocks = (B + 64 / FB_MINV_L - 1) / (64 / FB_MINV_L);
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv_bpass: B too large");
+  hipError_t e = hipMemsetAsync(Minv, 0, (size_t)B * NV * NV * sizeof(T), (hipStream_t)stream);      // entries outside the subtrees stay zero (:700-708)
+  if (e == hipSuccess) e = hipMemsetAsync(F, 0, (size_t)B * NV * 6 * NV * sizeof(T), (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "rbd_minv_bpass (clear)");
+  hipLaunchKernelGGL((fb_minv_bpass_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, Minv, F, U, Dinv);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_minv_bpass (floating base) launch");
+}
+template <class T>
+int minv_fpass_fb_launch(const T* q, int64_t B, T* Minv, T* F, const T* U, const T* Dinv, void* stream) {
+  using namespace rbdk;
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv_fpass: B < 0");
+  if (B == 0) return 0;
+  if (!q || !Minv || !F || !U || !Dinv) return fail(RBD_ERR_ARG, "rbd_minv_fpass: null argument");
+  const int64_t blocks = (B + FBP_C - 1) / FBP_C;
+  if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv_fpass: B too large");
+  hipLaunchKernelGGL((fb_minv_fpass_kernel<T>), dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, q, (long long)B, Minv, F, U, Dinv);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_minv_fpass (floating base) launch");
+}
+// forward_dynamics_grad (:1376-1384): forward dynamics, rnea_grad at that qdd, one batched product.
+// workspace: c [B, NV] | Minv [B, NV, NV] | qdd [B, NV] | dc_du [B, NV, 2 NV]
+template <class T>
+size_t fdg_fb_bytes(int64_t B) {
+  using namespace rbdk;
+  return align16((size_t)B * NV * sizeof(T)) + align16((size_t)B * NV * NV * sizeof(T)) + align16((size_t)B * NV * sizeof(T)) +
+         align16((size_t)B * NV * 2 * NV * sizeof(T));
+}
+template <class T>
+int fdg_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd_out, T* dqdd_du, void* workspace, size_t wsb, void* stream) {
+  using namespace rbdk;
+  if constexpr (N < 6) return grad_pass_needs_six("rbd_forward_dynamics_grad");
+  if (B < 0) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B < 0");
+  if (B == 0) return 0;
+  if (!q || !qd || !u || !dqdd_du) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: q, qd, u, dqdd_du must be non-null");
+  if (misaligned(dqdd_du) || misaligned(qdd_out)) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: output buffers must be 16-byte aligned");
+  if (!workspace || wsb < fdg_fb_bytes<T>(B)) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics_grad: workspace missing or smaller than rbd_fd_workspace_bytes()");
+  if (misaligned(workspace)) return fail(RBD_ERR_WORKSPACE, "rbd_forward_dynamics_grad: workspace must be 16-byte aligned");
+  char* w = reinterpret_cast<char*>(workspace);
+  size_t o = 0;
+  T* c = reinterpret_cast<T*>(w + o); o += align16((size_t)B * NV * sizeof(T));
+  T* Mi = reinterpret_cast<T*>(w + o); o += align16((size_t)B * NV * NV * sizeof(T));
+  T* qdd_ws = reinterpret_cast<T*>(w + o); o += align16((size_t)B * NV * sizeof(T));
+  T* dc = reinterpret_cast<T*>(w + o);
+  T* qdd = qdd_out ? qdd_out : qdd_ws;
+  int rc;
+  if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
+  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream)) != 0) return rc;                                               // :1373, :1381
+  const int64_t ab = ((int64_t)B * NV + 255) / 256;
+  if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
+  hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
+  if ((rc = grad_fb_launch<T>("rbd_forward_dynamics_grad", q, qd, (const T*)qdd, gravity, 0, B, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr, dc, stream)) != 0) return rc;   // :1378
+  const int64_t mb = ((int64_t)B * NV * 2 * NV + 255) / 256;
+  if (mb > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
+  hipLaunchKernelGGL((fb_neg_mm_kernel<T>), dim3((unsigned)mb), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);   // :1382-1383
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_forward_dynamics_grad (floating base) launch");
 }
 }  // namespace
 
@@ -202,8 +341,12 @@ __attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f64(void);
                                  void* stream) {                                                                            \
     return fd_fb_launch<T>(q, qd, u, gravity, B, qdd, ws, wsb, stream);                                                     \
   }                                                                                                                         \
-  int rbd_rnea_fpass_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_fpass"); } \
-  int rbd_rnea_bpass_##SFX(const T*, T*, int64_t, T*, void*) { return unsupported("rbd_rnea_bpass"); }                      \
+  int rbd_rnea_fpass_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* v, T* a, T* f, void* stream) {   \
+    return rnea_pass_fb_launch<T>(1, q, qd, qdd, gravity, B, nullptr, v, a, f, stream);                                     \
+  }                                                                                                                         \
+  int rbd_rnea_bpass_##SFX(const T* q, T* f, int64_t B, T* c, void* stream) {                                               \
+    return rnea_pass_fb_launch<T>(2, q, nullptr, nullptr, T(0), B, c, nullptr, nullptr, f, stream);                         \
+  }                                                                                                                         \
   int rbd_rnea_grad_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* dc_du, void* stream) { \
     return grad_fb_launch<T>("rbd_rnea_grad", q, qd, qdd, gravity, use_damping, B, c, nullptr, nullptr, nullptr, dc_du, stream); \
   }                                                                                                                         \
@@ -211,16 +354,29 @@ __attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f64(void);
                                T* dc_du, void* stream) {                                                                    \
     return grad_fb_launch<T>("rbd_rnea_with_grad", q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);          \
   }                                                                                                                         \
-  int rbd_rnea_grad_fpass_dq_##SFX(const T*, const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_grad_fpass_dq"); } \
-  int rbd_rnea_grad_fpass_dqd_##SFX(const T*, const T*, const T*, int64_t, T*, T*, T*, void*) { return unsupported("rbd_rnea_grad_fpass_dqd"); } \
-  int rbd_rnea_grad_bpass_dq_##SFX(const T*, const T*, T*, int64_t, T*, void*) { return unsupported("rbd_rnea_grad_bpass_dq"); } \
-  int rbd_rnea_grad_bpass_dqd_##SFX(const T*, T*, int, int64_t, T*, void*) { return unsupported("rbd_rnea_grad_bpass_dqd"); } \
-  int rbd_minv_bpass_##SFX(const T*, int64_t, T*, T*, T*, T*, void*) { return unsupported("rbd_minv_bpass"); }              \
-  int rbd_minv_fpass_##SFX(const T*, int64_t, T*, T*, const T*, const T*, void*) { return unsupported("rbd_minv_fpass"); }  \
+  int rbd_rnea_grad_fpass_dq_##SFX(const T* q, const T* qd, const T* v, const T* a, T gravity, int64_t B, T* dv, T* da, T* df, void* stream) { \
+    return grad_fpass_fb_launch<T, false>(q, qd, v, a, gravity, B, dv, da, df, stream);                                     \
+  }                                                                                                                         \
+  int rbd_rnea_grad_fpass_dqd_##SFX(const T* q, const T* qd, const T* v, int64_t B, T* dv, T* da, T* df, void* stream) {    \
+    return grad_fpass_fb_launch<T, true>(q, qd, v, nullptr, T(0), B, dv, da, df, stream);                                   \
+  }                                                                                                                         \
+  int rbd_rnea_grad_bpass_dq_##SFX(const T* q, const T* f, T* df, int64_t B, T* dc, void* stream) {                         \
+    return grad_bpass_fb_launch<T, false>(q, f, df, 0, B, dc, stream);                                                      \
+  }                                                                                                                         \
+  int rbd_rnea_grad_bpass_dqd_##SFX(const T* q, T* df, int use_damping, int64_t B, T* dc, void* stream) {                   \
+    return grad_bpass_fb_launch<T, true>(q, nullptr, df, use_damping, B, dc, stream);                                       \
+  }                                                                                                                         \
+  int rbd_minv_bpass_##SFX(const T* q, int64_t B, T* Minv, T* F, T* U, T* Dinv, void* stream) {                             \
+    return minv_bpass_fb_launch<T>(q, B, Minv, F, U, Dinv, stream);                                                         \
+  }                                                                                                                         \
+  int rbd_minv_fpass_##SFX(const T* q, int64_t B, T* Minv, T* F, const T* U, const T* Dinv, void* stream) {                 \
+    return minv_fpass_fb_launch<T>(q, B, Minv, F, U, Dinv, stream);                                                         \
+  }                                                                                                                         \
   int rbd_crba_##SFX(const T*, int64_t, T*, void*) { return unsupported("rbd_crba"); }                                      \
   int rbd_aba_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*) { return unsupported("rbd_aba"); }                 \
-  int rbd_forward_dynamics_grad_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, void*, size_t, void*) {             \
-    return unsupported("rbd_forward_dynamics_grad");                                                                        \
+  int rbd_forward_dynamics_grad_##SFX(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, T* dqdd_du, void* ws, \
+                                      size_t wsb, void* stream) {                                                           \
+    return fdg_fb_launch<T>(q, qd, u, gravity, B, qdd, dqdd_du, ws, wsb, stream);                                           \
   }
 
 #ifdef RBD_TU_FB_F32

@@ -58,7 +58,9 @@ RBD_DEV void fbw_flush_flat(const T* img, T* gdst, int lane, int nvalid) {
   }
 }
 
-template <class T, bool HAS_QDD>
+// MODE 0: rnea.  MODE 1: rnea_fpass (:559-598): v, a and the LOCAL f, no backward pass.  MODE 2: rnea_bpass
+// (:600-621): f [B, 6, N] is read from f_out, accumulated and written back in place, c out.
+template <class T, bool HAS_QDD, int MODE = 0>
 __global__ __launch_bounds__(64, 1) void rnea_fbw_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                          const T* __restrict__ qdd, T grav, long long B,
                                                          T* __restrict__ c_out, T* __restrict__ v_out,
@@ -70,18 +72,22 @@ __global__ __launch_bounds__(64, 1) void rnea_fbw_kernel(const T* __restrict__ q
   const long long rem = B - cfg0;
   const int nvalid = rem < 64 ? (int)rem : 64;
   const long long b = cfg0 + (lane < nvalid ? lane : nvalid - 1);
-  const T* qb = q + b * NV; const T* qdb = qd + b * NV; const T* qddb = HAS_QDD ? qdd + b * NV : nullptr;
+  const T* qb = q + b * NV; const T* qdb = MODE == 2 ? nullptr : qd + b * NV; const T* qddb = HAS_QDD ? qdd + b * NV : nullptr;
   constexpr int K6 = 6 * N;
   JTrig<T> tr[N];
   T qdv[N], qddv[N];
   sfor<1, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     tr[j] = make_trig<j>(qb[j + 5]);
-    qdv[j] = qdb[j + 5];
-    if constexpr (HAS_QDD) qddv[j] = qddb[j + 5]; else qddv[j] = T(0);
+    if constexpr (MODE != 2) {
+      qdv[j] = qdb[j + 5];
+      if constexpr (HAS_QDD) qddv[j] = qddb[j + 5]; else qddv[j] = T(0);
+    }
   });
   T v[N][6], a[N][6], f[N][6];
-  {
+  if constexpr (MODE == 2) {
+    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; f[j][r] = f_out[b * K6 + r * N + j]; }); });
+  } else {
     // the base (:576-596 with the floating-base lines :585, :591): v_0 = qd[0:6]; a_0 = X_0 a_grav + qdd[0:6]
     T E[3][3];
     fb_base_E(qb[3], qb[4], qb[5], E);
@@ -97,12 +103,14 @@ __global__ __launch_bounds__(64, 1) void rnea_fbw_kernel(const T* __restrict__ q
     sfor<0, 6>([&](auto R) { f[0][decltype(R)::value] = Ia[decltype(R)::value]; });
     fxv<true>(v[0], Iv, f[0]);
   }
+  if constexpr (MODE != 2) {
   sfor<1, N>([&](auto J) {
     constexpr int j = decltype(J)::value;
     constexpr int p = PARENT[j];
     T xv[6], xa[6];
     rnea_fwd_body<j, HAS_QDD>(tr[j], qdv[j], qddv[j], grav, v[p], a[p], xv, xa, v[j], a[j], f[j]);
   });
+  }
   // a [B, 6, N] tensor of 64 configurations through the image: element (r, j) of configuration `lane` at lane * 6N + r * N + j
   auto put6 = [&](const T (&x)[N][6], T* gdst) {
     FBW_WAVE_SYNC();                                           // the previous image has been read
@@ -115,9 +123,15 @@ __global__ __launch_bounds__(64, 1) void rnea_fbw_kernel(const T* __restrict__ q
     FBW_WAVE_SYNC();
     fbw_flush_flat<K6>(img, gdst + cfg0 * K6, lane, nvalid);
   };
-  if (v_out != nullptr) {
-    put6(v, v_out);
-    put6(a, a_out);
+  if constexpr (MODE != 2) {
+    if (v_out != nullptr) {
+      put6(v, v_out);
+      put6(a, a_out);
+    }
+  }
+  if constexpr (MODE == 1) {
+    put6(f, f_out);                                            // the local forces: no backward pass
+    return;
   }
   // backward pass (:607-619)
   T c[NV];

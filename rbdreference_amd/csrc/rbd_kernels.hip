@@ -2659,9 +2659,10 @@ size_t rbd_minv_workspace_bytes(int64_t B, int elem_size) {
 }
 size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {
   if (B <= 0) return 0;
-  if (rbdm::FLOATING_BASE) {      // c [B, NV] + Minv [B, NV, NV]  (rbd_fb_kernels.hip)
-    if (elem_size != 4 && elem_size != 8) return 0;
-    return align16((size_t)B * rbdm::NV * elem_size) + align16((size_t)B * rbdm::NV * rbdm::NV * elem_size);
+  if (rbdm::FLOATING_BASE) {      // c [B, NV] | Minv [B, NV, NV] | qdd [B, NV] | dc_du [B, NV, 2 NV]  (rbd_fb_kernels.hip; the
+    if (elem_size != 4 && elem_size != 8) return 0;   // last two serve forward_dynamics_grad only)
+    return align16((size_t)B * rbdm::NV * elem_size) + align16((size_t)B * rbdm::NV * rbdm::NV * elem_size) +
+           align16((size_t)B * rbdm::NV * elem_size) + align16((size_t)B * rbdm::NV * 2 * rbdm::NV * elem_size);
   }
   if (elem_size == 4) return FdWorkspace<float>(B).total;
   if (elem_size == 8) return FdWorkspace<double>(B).total;

@@ -381,7 +381,8 @@ class FloatingBaseRobot:
         return self.inner.get_subtree_by_id(i)
 
     def get_damping_by_id(self, i: int) -> float:
-        return 0.0 if i == 0 else self.inner.get_damping_by_id(i)
+        # the base's value feeds the reference's 5 x 5 damping block (RBDReference.py:1336-1339)
+        return self.inner.get_damping_by_id(i)
 
     def __repr__(self) -> str:
         return f"FloatingBaseRobot({self.name!r}, NB={self._n}, n={self._n + 5})"

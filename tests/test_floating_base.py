@@ -37,6 +37,21 @@ def test_fb_oracle_vs_reference_golden(name):
         assert rel_err(fbo.rnea_grad(m, g["q"], g["qd"]), g["dc_du_noqdd"]) <= TOL
         assert rel_err(fbo.rnea_grad(m, g["q"], g["qd"], g["qdd"], USE_VELOCITY_DAMPING=True), g["dc_du_damped"]) <= TOL
         assert fbo.rnea_grad(m, g["q"][1], g["qd"][1], g["qdd"][1]).shape == (m.n, 2 * m.n)
+        # the four gradient passes and forward_dynamics_grad (the reference runs them on floating bases: README.md:19)
+        dv, da, df = fbo.rnea_grad_fpass_dq(m, g["q"], g["qd"], g["fpass_v"], g["fpass_a"])
+        for k, x in (("dq_dv", dv), ("dq_da", da), ("dq_df", df)):
+            assert rel_err(x, g[k]) <= TOL, k
+        dv, da, df = fbo.rnea_grad_fpass_dqd(m, g["q"], g["qd"], g["fpass_v"])
+        for k, x in (("dqd_dv", dv), ("dqd_da", da), ("dqd_df", df)):
+            assert rel_err(x, g[k]) <= TOL, k
+        dc, dfa = fbo.rnea_grad_bpass_dq(m, g["q"], g["f_acc"], g["dq_df"])
+        assert rel_err(dc, g["dc_dq"]) <= TOL and rel_err(dfa, g["dq_df_after"]) <= TOL
+        dc, dfa = fbo.rnea_grad_bpass_dqd(m, g["q"], g["dqd_df"])
+        assert rel_err(dc, g["dc_dqd"]) <= TOL and rel_err(dfa, g["dqd_df_after"]) <= TOL
+        assert rel_err(fbo.rnea_grad_bpass_dqd(m, g["q"], g["dqd_df"], True)[0], g["dc_dqd_damped"]) <= TOL
+        a1, a2 = fbo.forward_dynamics_grad(m, g["q"], g["qd"], g["qdd"])
+        assert rel_err(a1, g["fd_dq"]) <= 1e-10 and rel_err(a2, g["fd_dqd"]) <= 1e-10
+        assert np.array_equal(np.hstack([g["dc_dq"][0], g["dc_dqd"][0]]), g["dc_du"][0])      # :1367
     else:
         assert "dc_du" not in g
         with pytest.raises(AssertionError):
@@ -208,14 +223,119 @@ def test_fb_unsupported_entry_points_say_so():
     from rbdreference_amd._lib import RBD_ERR_UNSUPPORTED, RbdError
     rbd = _rbd("fb_quadruped_like")
     q = torch.zeros((4, rbd.nv), device="cuda:0", dtype=torch.float32)
-    for call in (lambda: rbd.crba(q), lambda: rbd.aba(q, q, q), lambda: rbd.forward_dynamics_grad(q, q, q)):
+    for call in (lambda: rbd.crba(q), lambda: rbd.aba(q, q, q)):      # the reference's own crba / aba raise (:1063, :900)
         with pytest.raises(RbdError) as ei:
             call()
         assert ei.value.code == RBD_ERR_UNSUPPORTED and "floating-base" in str(ei.value)
     # fewer than six bodies: the reference's own rnea_grad raises IndexError (:1168, on record in the fixture)
     small = _rbd("fb_random_tree_n4")
     q = torch.zeros((4, small.nv), device="cuda:0", dtype=torch.float64)
-    for call in (lambda: small.rnea_grad(q, q, q), lambda: small.rnea_and_grad(q, q, q)):
+    v = torch.zeros((4, 6, small.n), device="cuda:0", dtype=torch.float64)
+    for call in (lambda: small.rnea_grad(q, q, q), lambda: small.rnea_and_grad(q, q, q), lambda: small.forward_dynamics_grad(q, q, q),
+                 lambda: small.rnea_grad_fpass_dq(q, q, v, v), lambda: small.rnea_grad_fpass_dqd(q, q, v)):
         with pytest.raises(RbdError) as ei:
             call()
         assert ei.value.code == RBD_ERR_UNSUPPORTED and "NB = 4" in str(ei.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", fb_golden_names())
+@pytest.mark.parametrize("dtname", ["f64", "f32"])
+def test_fb_passes_vs_golden(name, dtname):
+    """The per-pass surface (README.md:19) for floating bases against the real reference's outputs: rnea_fpass /
+    rnea_bpass (in-place f), the four gradient passes (in-place df), minv_bpass / minv_fpass, forward_dynamics_grad."""
+    import torch
+    dt = torch.float64 if dtname == "f64" else torch.float32
+    tol = 1e-11 if dt == torch.float64 else 1e-5
+    g = load_golden(name); rbd = _rbd(name)
+    T = lambda x: torch.tensor(np.ascontiguousarray(x), device="cuda:0", dtype=dt)
+    q, qd, qdd = T(g["q"]), T(g["qd"]), T(g["qdd"])
+
+    def chk(nm, got, want, t=tol):
+        e = rel_err_rows(got.double().cpu().numpy(), want)
+        assert e <= t, f"{nm}: {e:.3e} > {t}"
+    v, a, f = rbd.rnea_fpass(q, qd, qdd)
+    chk("fpass_v", v, g["fpass_v"]); chk("fpass_a", a, g["fpass_a"]); chk("fpass_f", f, g["fpass_f"])
+    f_in = T(g["fpass_f"])
+    c, f_ret = rbd.rnea_bpass(q, f_in)
+    assert f_ret is f_in                                                   # accumulated IN PLACE (:619)
+    chk("c", c, g["c"]); chk("f_acc", f_in, g["f_acc"])
+    Mb, F, U, D = rbd.minv_bpass(q)
+    chk("mb_Minv", Mb, g["mb_Minv"]); chk("mb_F", F, g["mb_F"]); chk("mb_U", U, g["mb_U"]); chk("mb_Dinv", D, g["mb_Dinv"])
+    Min = T(g["mb_Minv"]); Fin = torch.full_like(T(g["mb_F"]), 7.0)        # F is rebuilt: its incoming values are not read (:774-781)
+    Mo = rbd.minv_fpass(q, Min, Fin, T(g["mb_U"]), T(g["mb_Dinv"]))
+    chk("minv_fpass", Mo, g["Minv_upper"])                                  # a floating base completes every row (:779)
+    if rbd.n < 6:
+        return
+    dv, da, df = rbd.rnea_grad_fpass_dq(q, qd, T(g["fpass_v"]), T(g["fpass_a"]))
+    chk("dq_dv", dv, g["dq_dv"]); chk("dq_da", da, g["dq_da"]); chk("dq_df", df, g["dq_df"])
+    dv, da, df = rbd.rnea_grad_fpass_dqd(q, qd, T(g["fpass_v"]))
+    chk("dqd_dv", dv, g["dqd_dv"]); chk("dqd_da", da, g["dqd_da"]); chk("dqd_df", df, g["dqd_df"])
+    dfin = T(g["dq_df"])
+    chk("dc_dq", rbd.rnea_grad_bpass_dq(q, T(g["f_acc"]), dfin), g["dc_dq"])
+    chk("dq_df after the pass", dfin, g["dq_df_after"])                    # (:1291-1294)
+    dfin = T(g["dqd_df"])
+    chk("dc_dqd", rbd.rnea_grad_bpass_dqd(q, dfin), g["dc_dqd"])
+    chk("dqd_df after the pass", dfin, g["dqd_df_after"])                  # (:1331)
+    chk("dc_dqd_damped", rbd.rnea_grad_bpass_dqd(q, T(g["dqd_df"]), True), g["dc_dqd_damped"])
+    # forward_dynamics_grad: fp32 is multiplied by Minv (cond 1e2..1e4): bound from cond(H) per row
+    a1, a2 = rbd.forward_dynamics_grad(q, qd, qdd)
+    if dt == torch.float64:
+        chk("fd_dq", a1, g["fd_dq"], 1e-9); chk("fd_dqd", a2, g["fd_dqd"], 1e-9)
+    else:
+        cond = np.array([np.linalg.cond(M) for M in g["Minv_dense"]])
+        for nm, got in (("fd_dq", a1), ("fd_dqd", a2)):
+            gn = got.double().cpu().numpy()
+            err = np.abs(gn - g[nm]).reshape(len(cond), -1).max(1) / np.abs(g[nm]).reshape(len(cond), -1).max(1)
+            assert np.all(err <= 16.0 * 2.0 ** -24 * cond), (nm, err, cond)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in fb_golden_names() if n != "fb_random_tree_n4"])
+def test_fb_both_gradient_kernels_vs_golden(name):
+    """rnea_grad on the world-frame kernel (AUTO) and on the column recursion (COLS), damped and not."""
+    import torch
+    from rbdreference_amd._lib import RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_COLS, RBD_OPT_GRAD_KERNEL
+    g = load_golden(name); rbd = _rbd(name)
+    try:
+        for opt, want_kernel in ((RBD_GRAD_KERNEL_AUTO, "rnea_grad_fbw_kernel"), (RBD_GRAD_KERNEL_COLS, "rnea_grad_fb_kernel")):
+            rbd._lib.set_option(RBD_OPT_GRAD_KERNEL, opt)
+            for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
+                assert rbd._lib.kernel_name(1, 8 if dt == torch.float64 else 4, 8).startswith(want_kernel)
+                q, qd, qdd = (torch.tensor(g[k], device="cuda:0", dtype=dt) for k in ("q", "qd", "qdd"))
+                for kw, key in (({}, "dc_du"), ({"USE_VELOCITY_DAMPING": True}, "dc_du_damped")):
+                    e = rel_err_rows(rbd.rnea_grad(q, qd, qdd, **kw).double().cpu().numpy(), g[key])
+                    assert e <= tol, (want_kernel, dt, key, e)
+                e = rel_err_rows(rbd.rnea_grad(q, qd).double().cpu().numpy(), g["dc_du_noqdd"])
+                assert e <= tol, (want_kernel, dt, "noqdd", e)
+    finally:
+        rbd._lib.set_option(RBD_OPT_GRAD_KERNEL, RBD_GRAD_KERNEL_AUTO)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtname", ["f32", "f64"])
+def test_fb_full_size_sampled_rows(dtname):
+    """B = 65 536 (the size the floating-base timings are quoted at): 256 sampled rows of every product against the
+    oracle, exact symmetry of Minv, and Minv (c(qdd) - c(0)) = qdd on every row."""
+    import torch
+    dt = torch.float64 if dtname == "f64" else torch.float32
+    tol = 1e-11 if dt == torch.float64 else 1e-5
+    name = "fb_quadruped_like"; B = 65536
+    rbd = _rbd(name); m = fbo.model_from_robot(make_robot(name))
+    rng = np.random.default_rng(77)
+    q = rng.uniform(-np.pi, np.pi, (B, m.n)); qd = rng.uniform(-1, 1, (B, m.n)); qdd = rng.uniform(-1, 1, (B, m.n))
+    tq, tqd, tqdd = (torch.tensor(x, device="cuda:0", dtype=dt) for x in (q, qd, qdd))
+    rows = rng.choice(B, 256, replace=False)
+    c, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    dc = rbd.rnea_grad(tq, tqd, tqdd)
+    Mi = rbd.minv(tq)
+    cr, vr, ar, fr = fbo.rnea(m, q[rows], qd[rows], qdd[rows])
+    for nm, got, want in (("c", c, cr), ("v", v, vr), ("a", a, ar), ("f", f, fr),
+                          ("dc_du", dc, fbo.rnea_grad(m, q[rows], qd[rows], qdd[rows])), ("Minv", Mi, fbo.minv(m, q[rows]))):
+        e = rel_err_rows(got[rows].double().cpu().numpy(), want)
+        assert e <= tol, (nm, e)
+    assert torch.equal(Mi, Mi.transpose(1, 2))
+    c0 = rbd.rnea(tq, tqd, torch.zeros_like(tqdd), outputs="c")[0]
+    back = torch.einsum("bij,bj->bi", Mi.double(), (c - c0).double())
+    err = (back - tqdd.double()).abs().amax(1) / tqdd.double().abs().amax(1)
+    assert float(err.max()) <= (1e-9 if dt == torch.float64 else 2e-2), float(err.max())
