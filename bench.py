@@ -308,6 +308,15 @@ def main():
                     traffic_note = tj.get("note")
             except Exception:
                 traffic = None
+        # the vector-pipe side of the roofline, from the SQ counters committed with the traffic file (same kernel, same
+        # sources): flops and instruction counts are per launch and do not depend on the box; the time is this run's
+        valu_frac = valu_tflops = valu_issue = None
+        if valu and valu.get("flops_per_launch"):
+            valu_tflops = valu["flops_per_launch"] / (kern_ms * 1e-3) / 1e12
+            valu_frac = valu_tflops / FP32_VALU_PEAK_TFLOPS
+            valu_issue = valu.get("simd_valu_busy_frac")
+        hbm_frac = achieved / HBM_PEAK_GBS
+        bound = "valu" if (valu_frac is not None and valu_frac > hbm_frac) else "hbm"
         out = {
             "metric": "batched RNEA+grad evals/s (7-DoF)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -320,14 +329,18 @@ def main():
                        "robot": "iiwa_like", "batch_per_gpu": rows_rank, "global_batch": rows_global,
                        "buffer_sets": nsets,
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_eval": BYTES_PER_EVAL, "kernel": kernel,
                          "kernel_ms": kern_ms, "sources_digest": digest, "valu": valu,
-                         "note": "HBM fraction from algorithmic bytes (SURVEY.md §8d: 504 B per evaluation); the "
-                                 "kernel's arithmetic (~4.8 k VALU wave-instructions per 64 evaluations) puts its "
-                                 "FP32-VALU floor at ~0.55 of this launch time, see `valu` when a matching SQ "
-                                 "profile is committed"},
+                         "valu_frac_of_peak": valu_frac, "valu_tflops": valu_tflops,
+                         "valu_peak_tflops": FP32_VALU_PEAK_TFLOPS, "valu_issue_frac": valu_issue,
+                         "note": "frac = algorithmic bytes (SURVEY.md §8d: 504 B per evaluation) / this run's launch time / "
+                                 "8 TB/s.  valu_frac_of_peak = fp32 flops per launch (2 x FMA + MUL + ADD + TRANS wave-"
+                                 "instructions x 64 lanes, from the committed SQ profile of this kernel and these "
+                                 "sources) / this run's launch time / 157.3 TFLOP/s; valu_issue_frac = all VALU "
+                                 "wave-instructions x 2 cycles per SIMD / launch cycles (what the vector pipe is busy); "
+                                 "`bound` names the larger of frac and valu_frac_of_peak"},
             "parity_max_rel_err_first_256_rows": parity,
         }
         if other is not None:
@@ -463,6 +476,27 @@ def main():
                     "ms_rnea_grad": t3, "alg_GBps_rnea_grad": Bf * (4 * nvf + 2 * nvf * nvf) * 4 / (t3 * 1e-3) / 1e9}
             except Exception as e:  # the headline line must still be printed
                 extra["error"] = repr(e)
+            try:
+                # the per-rank launch of configs[3] at N = 8: 131 072 rows, kernel selection pinned to the global batch
+                # as ShardedRBD does (a prediction the first real 8-GPU SCALE run can be checked against)
+                Bs = (1 << 20) // 8
+                qs, qds, qdds = (x[:Bs].contiguous() for x in (q, qd, qdd))
+                with rbd.shard_of(1 << 20):
+                    ss = GradStep(rbd, [(qs, qds, qdds)])
+                    ms = time_extra_ms(ss, 50, 10)
+                    kn = rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, Bs)
+                extra["cfg3_per_rank_shard_B131072_of_1M_f32"] = {
+                    "ms_per_launch": ms, "evals_per_s": Bs / (ms * 1e-3), "alg_GBps": Bs * BYTES_PER_EVAL / (ms * 1e-3) / 1e9,
+                    "kernel": kn, "predicted_8gpu_strong_scaling_evals_per_s": (1 << 20) / (ms * 1e-3),
+                    "note": "one rank's share of the 1 048 576-row global batch; 8 ranks run it concurrently with no "
+                            "data-path collective, so the N = 8 strong-scaling value is bounded by (1 M rows) / this time"}
+                del ss
+            except Exception as e:
+                extra["cfg3_shard_error"] = repr(e)
+            for ent in extra.values():            # every algorithmic rate also as a fraction of the 8 TB/s HBM peak
+                if isinstance(ent, dict):
+                    for k in [k for k in ent if k.startswith("alg_GBps")]:
+                        ent["frac" + k[len("alg_GBps"):]] = ent[k] / HBM_PEAK_GBS
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(robot, 3)

@@ -83,12 +83,18 @@ int rbd_model_info(rbd_model_info_t* out);
  *                          wave per independent root subtree).  AUTO: robots whose root subtrees carry
  *                          several big branches (Atlas' arms) get one wave per branch / stem / root
  *                          subtree, other multi-root robots GROUPS, single chains BATCH
+ *   RBD_OPT_SELECT_BATCH   rows of the GLOBAL batch a call is a shard of (0 = the call's own B, the default).
+ *                          Wherever AUTO decides from the batch size (the small-batch column kernel of
+ *                          rbd_rnea_grad, phase A of rbd_minv), it decides from this number instead: a shard of
+ *                          a sharded batch then runs the kernel the unsharded call would run, so sharded and
+ *                          unsharded results are bit-identical row by row (rbdreference_amd.dist.ShardedRBD sets it)
  * rbd_kernel_name writes the name of the kernel (the dominant one of a multi-launch entry point) that
  * `op` would launch for a batch of B rows of elem_size-byte scalars under the current options. */
 #define RBD_OPT_GRAD_KERNEL 0
 #define RBD_OPT_MINV_PHASE_A 1
 #define RBD_OPT_RNEA_KERNEL 2
-#define RBD_OPT_COUNT_ 3
+#define RBD_OPT_SELECT_BATCH 3
+#define RBD_OPT_COUNT_ 4
 #define RBD_GRAD_KERNEL_AUTO 0
 #define RBD_GRAD_KERNEL_TREE 1
 #define RBD_GRAD_KERNEL_COLS 2

@@ -16,7 +16,7 @@ from .packer import ABI_VERSION, PackedModel
 RBD_MAX_BODIES = 64
 RBD_ERR_ARG, RBD_ERR_UNSUPPORTED, RBD_ERR_WORKSPACE = -1, -2, -3
 # rbd_set_option / rbd_kernel_name constants (include/rbd_hip.h)
-RBD_OPT_GRAD_KERNEL, RBD_OPT_MINV_PHASE_A, RBD_OPT_RNEA_KERNEL = 0, 1, 2
+RBD_OPT_GRAD_KERNEL, RBD_OPT_MINV_PHASE_A, RBD_OPT_RNEA_KERNEL, RBD_OPT_SELECT_BATCH = 0, 1, 2, 3
 RBD_RNEA_KERNEL_AUTO, RBD_RNEA_KERNEL_BATCH, RBD_RNEA_KERNEL_GROUPS = 0, 1, 2
 RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_TREE, RBD_GRAD_KERNEL_COLS, RBD_GRAD_KERNEL_BATCH = 0, 1, 2, 3
 RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_MINV_PHASE_A_IA8, RBD_MINV_PHASE_A_FUSED = 0, 1, 2, 3

@@ -10,6 +10,7 @@ library every call raises.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import numpy as np
@@ -28,6 +29,23 @@ class RBDReference:
         self._lib = RbdLibrary(self.model, build=build)
         self.n = self.model.n            # bodies
         self.nv = self.model.nv          # columns of q, qd, qdd, c: n, or n + 5 with a floating base
+
+    @contextlib.contextmanager
+    def shard_of(self, global_rows: int):
+        """Declare that the calls inside the block evaluate SHARDS of a global batch of ``global_rows`` rows: wherever
+        the library picks a kernel from the batch size it then decides from the global size (``RBD_OPT_SELECT_BATCH``,
+        include/rbd_hip.h), so a shard is computed by the same kernel -- and is bit-identical, row by row -- as the
+        unsharded call.  Process-wide like every option; restored on exit."""
+        from ._lib import RBD_OPT_SELECT_BATCH
+        g = int(global_rows)
+        if not (0 <= g < 2 ** 31):
+            raise ValueError("global_rows must be in [0, 2^31)")
+        old = self._lib.get_option(RBD_OPT_SELECT_BATCH)
+        self._lib.set_option(RBD_OPT_SELECT_BATCH, g)
+        try:
+            yield self
+        finally:
+            self._lib.set_option(RBD_OPT_SELECT_BATCH, old)
 
     # ------------------------------------------------------------------------------------
     def _prep(self, *arrs):

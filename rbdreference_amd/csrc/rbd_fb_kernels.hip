@@ -114,11 +114,11 @@ int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gra
         if (qdd) {
           auto k = rnea_grad_fbw_kernel<T, true>;
           if ((rc = ensure_lds(k, lds)) != 0) return rc;
-          hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+          hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * FBW_W), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
         } else {
           auto k = rnea_grad_fbw_kernel<T, false>;
           if ((rc = ensure_lds(k, lds)) != 0) return rc;
-          hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
+          hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * FBW_W), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping, (long long)B, cg, dc_du);
         }
       }
     } else {

@@ -154,10 +154,10 @@ __global__ __launch_bounds__(64, 1) void rnea_fbw_kernel(const T* __restrict__ q
 // ---------------------------------------------------------------------------------------------------------
 // rnea_grad (floating base), world frame
 // ---------------------------------------------------------------------------------------------------------
-// LDS plan (scalars of T): [0, 64 * FBW_KP) the row image; then lane-private columns (slot * 64 + lane):
+// LDS plan (scalars of T): [0, FBW_W * 64 * FBW_KP) one row image per wave; then lane-private columns (slot * 64 + lane):
 //   FBW_PAIR  (jj, j) with jj >= 1 a proper ancestor of j: the column entries (dq, dqd) of row jj     2 per pair
 //   FBW_BASE  (k, j), k < 6, j >= 1: the entries (dq, dqd) of base row k in the columns of body j       12 (N - 1)
-//   FBW_PARK  composites of finished chains (heads with a parent)                                      31 per chain
+//   FBW_PARK  composites of finished chains (heads with a parent) that do not wait in a wave's image     31 per chain
 constexpr int fbw_pairs_before(int j) {          // pairs (jj, x) with x < j
   int k = 0;
   for (int x = 1; x < j; ++x)
@@ -172,12 +172,56 @@ constexpr int fbw_pair_rank(int jj, int j) {     // jj >= 1 a proper ancestor of
 constexpr int FBW_NPAIRS = fbw_pairs_before(N);
 constexpr int FBW_ROW = 2 * NV;
 constexpr int FBW_KP = (NV % 2 == 0) ? 4 * ((NV / 2) | 1) : 2 * NV;   // row stride: odd in units of the flush vector
+// One block = 64 configurations x FBW_W waves.  The subtrees hanging off the base are independent of each other
+// until the base itself is built, so each gets a wave (round-robin when there are more than FBW_W_MAX of them);
+// the one that continues the base's chain (its heavy child) runs on wave 0, which then builds the base.  The
+// waves share the lane-private LDS columns (same lane = same configuration): pending entries and parked
+// composites of one wave are read by another across ONE block barrier -- wave 0 passes it just before it builds
+// the base, every other wave when its chains are done (s_barrier counts arrivals).
+constexpr int FBW_W_MAX = 4;
+constexpr int fbw_child_root(int j) {            // the child of the base that body j >= 1 hangs under
+  while (PARENT[j] != 0) j = PARENT[j];
+  return j;
+}
+constexpr int fbw_n_children() {
+  int k = 0;
+  for (int j = 1; j < N; ++j) k += PARENT[j] == 0 ? 1 : 0;
+  return k;
+}
+constexpr int FBW_W = fbw_n_children() < FBW_W_MAX ? (fbw_n_children() < 1 ? 1 : fbw_n_children()) : FBW_W_MAX;
+constexpr int fbw_wave_of_child(int r) {         // r: a child of the base
+  if (TP.heavy[0] == r) return 0;
+  int k = 0;                                     // ordinal among the other children
+  for (int j = 1; j < r; ++j) k += (PARENT[j] == 0 && TP.heavy[0] != j) ? 1 : 0;
+  return FBW_W == 1 ? 0 : 1 + k % (FBW_W - 1);
+}
+constexpr int fbw_wave_of(int h) { return h == 0 ? 0 : fbw_wave_of_child(fbw_child_root(h)); }
+// A child subtree's composite waits for the base in the row image of ITS wave (free once that wave's last row has
+// been flushed) when that wave runs no other child subtree; everything else parks in the FBW_PARK area.
+constexpr int fbw_children_on_wave(int w) {
+  int k = 0;
+  for (int j = 1; j < N; ++j) k += (PARENT[j] == 0 && fbw_wave_of_child(j) == w) ? 1 : 0;
+  return k;
+}
+constexpr bool fbw_park_in_image(int h) {        // h: a chain head with a parent
+  return PARENT[h] == 0 && fbw_wave_of_child(h) != 0 && fbw_children_on_wave(fbw_wave_of_child(h)) == 1 && TREE_COMP_SCALARS <= 2 * NV;
+}
+constexpr int fbw_area_parks() {
+  int k = 0;
+  for (int h = 1; h < N; ++h) k += (is_chain_head(h) && !fbw_park_in_image(h)) ? 1 : 0;
+  return k;
+}
+constexpr int fbw_area_rank(int h) {
+  int k = 0;
+  for (int x = 1; x < h; ++x) k += (is_chain_head(x) && !fbw_park_in_image(x)) ? 1 : 0;
+  return k;
+}
 constexpr int FBW_PAIR = 0;
 constexpr int FBW_BASE = FBW_PAIR + 2 * FBW_NPAIRS;
 constexpr int FBW_PARK = FBW_BASE + 12 * (N - 1);
-constexpr int FBW_PRIV = FBW_PARK + TREE_COMP_SCALARS * n_parked_chains();
+constexpr int FBW_PRIV = FBW_PARK + TREE_COMP_SCALARS * fbw_area_parks();
 template <class T>
-constexpr size_t fbw_lds_bytes() { return sizeof(T) * (size_t)64 * (FBW_KP + FBW_PRIV); }
+constexpr size_t fbw_lds_bytes() { return sizeof(T) * (size_t)64 * (FBW_W * FBW_KP + FBW_PRIV); }
 constexpr bool fbw_model_ok_() {
   if (N < 6) return false;                                  // the reference raises below six bodies (:1168)
   for (int j = 1; j < N; ++j) {
@@ -235,13 +279,19 @@ RBD_DEV T fbw_dot_col(const T (&x)[6], const T (&sk)[6]) {
 }
 
 template <class T, bool HAS_QDD>
-__global__ __launch_bounds__(64, 1) void rnea_grad_fbw_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+__global__ __launch_bounds__(64 * FBW_W, 1) void rnea_grad_fbw_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                               const T* __restrict__ qdd, T grav, int use_damping,
                                                               long long B, T* __restrict__ c_out, T* __restrict__ dcdu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x;
-  T* rowimg = reinterpret_cast<T*>(smem_raw);                       // [64][FBW_KP]
-  T* priv = reinterpret_cast<T*>(smem_raw) + 64 * FBW_KP + lane;    // priv[slot * 64]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T* rowimg = reinterpret_cast<T*>(smem_raw) + wave * (64 * FBW_KP);             // [64][FBW_KP], one per wave
+  T* priv = reinterpret_cast<T*>(smem_raw) + FBW_W * 64 * FBW_KP + lane;         // priv[slot * 64], shared by the waves
+  // where the composite of chain h waits: its wave's image (slot * 64 + lane, like the private columns) or the park area
+  auto park_at = [&](auto H_, int slot) -> T* {
+    constexpr int hh = decltype(H_)::value;
+    if constexpr (fbw_park_in_image(hh)) return reinterpret_cast<T*>(smem_raw) + fbw_wave_of(hh) * (64 * FBW_KP) + slot * 64 + lane;
+    else return priv + (FBW_PARK + TREE_COMP_SCALARS * fbw_area_rank(hh) + slot) * 64;
+  };
   const long long cfg0 = (long long)blockIdx.x * 64;
   const long long rem = B - cfg0;
   const int nvalid = rem < 64 ? (int)rem : 64;
@@ -306,6 +356,7 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_fbw_kernel(const T* __restric
   sfor_down<0, N>([&](auto H_) {
     constexpr int h = decltype(H_)::value;
     if constexpr (is_chain_head(h)) {
+     if (wave == fbw_wave_of(h)) {
       constexpr int leaf = chain_leaf(h);
       // ---- inputs and trig of the root path of this chain; the base's state and columns ------------------
       JTrig<T> tr[N];
@@ -342,12 +393,14 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_fbw_kernel(const T* __restric
             comp_local<j>(s, L);
             comp_add(C, L);
           }
+          // the other waves' subtrees (composites, base-row entries) are complete behind this barrier
+          if constexpr (j == 0 && FBW_W > 1) __syncthreads();
           // finished chains hanging off this body (:1446-1448)
           sfor<0, N>([&](auto K_) {
             constexpr int kk = decltype(K_)::value;
             if constexpr (PARENT[kk] == j && is_chain_head(kk) && kk != j) {
               Comp<T> P;
-              comp_each(P, [&](auto I_, T& x) { x = priv[(FBW_PARK + TREE_COMP_SCALARS * park_rank(kk) + decltype(I_)::value) * 64]; });
+              comp_each(P, [&](auto I_, T& x) { x = *park_at(K_, decltype(I_)::value); });
               comp_add(C, P);
             }
           });
@@ -415,7 +468,8 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_fbw_kernel(const T* __restric
             if constexpr (j != h) {
               ws_up<j>(s, tr[j], qdv[j], qddv[j], Sv[j], Pd[j]);
             } else {
-              comp_each(C, [&](auto I_, T& x) { priv[(FBW_PARK + TREE_COMP_SCALARS * park_rank(h) + decltype(I_)::value) * 64] = x; });
+              FBW_WAVE_SYNC();                               // (an image park: the row just flushed has been read)
+              comp_each(C, [&](auto I_, T& x) { *park_at(H_, decltype(I_)::value) = x; });
             }
           } else {
             // ---- the base: c[0:6] and its six rows (s now holds the base's state again) ----------------------
@@ -454,8 +508,12 @@ __global__ __launch_bounds__(64, 1) void rnea_grad_fbw_kernel(const T* __restric
           }
         }
       });
+     }
     }
   });
+  if constexpr (FBW_W > 1) {
+    if (wave != 0) __syncthreads();                          // wave 0 passed its barrier before it built the base
+  }
 }
 
 }  // namespace rbdk

@@ -1919,6 +1919,11 @@ extern "C" std::atomic<int>* rbd_option_slot(int option) {
 }
 #endif
 static inline int rbd_option(int option) { return rbd_option_slot(option)->load(std::memory_order_relaxed); }
+// the batch size kernel selection looks at: the call's own, unless the caller has declared the global batch it is a shard of
+static inline int64_t rbd_select_batch(int64_t B) {
+  const int g = rbd_option(RBD_OPT_SELECT_BATCH);
+  return g > 0 ? (int64_t)g : B;
+}
 
 // The forward-dynamics units reuse the kernels of the RNEA / MINV / GRAD units through these entry
 // points instead of instantiating the same templates a second time (Atlas: the fp64 gradient kernel
@@ -2180,7 +2185,7 @@ inline bool grad_use_cols(int64_t B) {
   const int opt = rbd_option(RBD_OPT_GRAD_KERNEL);
   if (opt == RBD_GRAD_KERNEL_COLS) return true;
   if (opt != RBD_GRAD_KERNEL_AUTO) return false;
-  return (B + GC_CPW - 1) / GC_CPW <= GRAD_COLS_MAX_WAVES;
+  return (rbd_select_batch(B) + GC_CPW - 1) / GC_CPW <= GRAD_COLS_MAX_WAVES;
 }
 template <class T, bool HAS_QDD>
 int grad_cols_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
@@ -2341,7 +2346,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (!workspace || wsb < need) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace missing or smaller than rbd_minv_workspace_bytes()");
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return fail(RBD_ERR_WORKSPACE, "rbd_minv: workspace must be 16-byte aligned");
   T* ws = reinterpret_cast<T*>(workspace);
-  const bool lane_a = pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && B >= 64 * 1024 * 4);
+  const bool lane_a = pa == RBD_MINV_PHASE_A_LANE || (pa != RBD_MINV_PHASE_A_IA8 && rbd_select_batch(B) >= 64 * 1024 * 4);
   const int64_t blocksA = (B + 63) / 64, blocksB = minv_cols_blocks(B, !lane_a);
   if (blocksB > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   if (lane_a) {
@@ -2609,7 +2614,7 @@ const char* rbd_last_error(void) { return rbd_err_buf(); }
 int rbd_set_option(int option, int value) {
   std::atomic<int>* s = rbd_option_slot(option);
   if (!s) return fail(RBD_ERR_ARG, "rbd_set_option: unknown option");
-  if (value < 0 || value > (option == RBD_OPT_RNEA_KERNEL ? 2 : 3))
+  if (value < 0 || (option != RBD_OPT_SELECT_BATCH && value > (option == RBD_OPT_RNEA_KERNEL ? 2 : 3)))
     return fail(RBD_ERR_ARG, "rbd_set_option: value out of range");
   s->store(value, std::memory_order_relaxed);
   return 0;

@@ -15,6 +15,7 @@ costs ~2.3 ms as a ring but is not on the default path at all.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Optional, Sequence, Tuple
 
 import torch
@@ -112,7 +113,11 @@ class ShardedRBD:
 
     ``compute`` maps local row shards to local outputs; by default it is the HIP-backed
     ``RBDReference`` of this rank.  (Tests inject a stand-in to exercise the sharding logic on CPU
-    with the gloo backend -- the product path has no CPU implementation.)"""
+    with the gloo backend -- the product path has no CPU implementation.)
+
+    Shards are evaluated under ``rbd.shard_of(B)``: kernel selection sees the GLOBAL batch size, so the rows a
+    rank returns are bit-identical to the same rows of an unsharded call whatever the number of ranks (without it
+    a 65 536-row batch over 8 ranks would put 8 192-row shards on the small-batch column kernel)."""
 
     def __init__(self, rbd=None, group=None, compute_rnea_grad: Optional[Callable] = None,
                  compute_minv: Optional[Callable] = None, model_hash: Optional[str] = None):
@@ -120,6 +125,7 @@ class ShardedRBD:
         self.group = group
         self._grad = compute_rnea_grad or (lambda q, qd, qdd, **kw: rbd.rnea_grad(q, qd, qdd, **kw))
         self._minv = compute_minv or (lambda q, **kw: rbd.minv(q, **kw))
+        self._pin = rbd.shard_of if (rbd is not None and hasattr(rbd, "shard_of")) else (lambda B: contextlib.nullcontext())
         check_same_model(model_hash or (rbd.model.hash if rbd is not None else ""), group)
 
     def local_slice(self, B: int) -> slice:
@@ -132,7 +138,8 @@ class ShardedRBD:
         dc_du, or all rows when ``gather=True``."""
         B = q.shape[0]
         sl = self.local_slice(B)
-        out = self._grad(q[sl], qd[sl], None if qdd is None else qdd[sl], **kw)
+        with self._pin(B):
+            out = self._grad(q[sl], qd[sl], None if qdd is None else qdd[sl], **kw)
         if not gather:
             return out
         if isinstance(out, tuple):            # return_c=True -> (c, dc_du): gather each
@@ -142,5 +149,6 @@ class ShardedRBD:
     def minv(self, q, gather: bool = False, **kw):
         B = q.shape[0]
         sl = self.local_slice(B)
-        out = self._minv(q[sl], **kw)
+        with self._pin(B):
+            out = self._minv(q[sl], **kw)
         return all_gather_rows(out, B, self.group) if gather else out

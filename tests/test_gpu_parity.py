@@ -723,7 +723,76 @@ def test_sharded_rbd_over_nccl():
                    LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dist_nccl_worker.py")], cwd=root, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    import time
+    deadline = time.time() + 600                  # ONE deadline for all ranks; nobody is left running on a failure
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=max(1.0, deadline - time.time()))[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.communicate()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}:\n{o[-3000:]}"
         assert "sharded ok" in o, o[-2000:]
+
+
+def test_shard_equals_rows_of_the_unsharded_call_bit_for_bit():
+    """a shard must equal the same rows of the unsharded call EXACTLY, whatever the number of ranks.
+    Kernel selection depends on the batch size (4 096-row shards of a 65 536-row batch would run the small-batch
+    column kernel, the unsharded call the batch-parallel one): `shard_of(global_rows)` -- what ShardedRBD wraps every
+    shard in -- pins the selection to the global size.  Checked here on one GPU by slicing."""
+    torch = _torch()
+    from rbdreference_amd import RBDReference
+    from rbdreference_amd.dist import ShardedRBD, shard_bounds
+    rbd = RBDReference(make_robot("iiwa_like"), build=False)
+    B = 65536
+    rng = np.random.default_rng(12)
+    q, qd, qdd = (torch.tensor(rng.uniform(-1, 1, (B, rbd.n)), device="cuda:0", dtype=torch.float32) for _ in range(3))
+    full = rbd.rnea_grad(q, qd, qdd)
+    full_minv = rbd.minv(q)
+    assert rbd._lib.kernel_name(1, 4, B) != rbd._lib.kernel_name(1, 4, 4096)     # the hazard is real for this robot
+    for world in (8, 16):
+        for rank in (0, world // 2, world - 1):
+            a, b = shard_bounds(B, world, rank)
+            with rbd.shard_of(B):
+                assert rbd._lib.kernel_name(1, 4, b - a) == rbd._lib.kernel_name(1, 4, B)
+                part = rbd.rnea_grad(q[a:b], qd[a:b], qdd[a:b])
+                part_minv = rbd.minv(q[a:b])
+            assert torch.equal(part, full[a:b]), (world, rank)
+            assert torch.equal(part_minv, full_minv[a:b]), (world, rank)
+    # ShardedRBD itself (world = 1 here) goes through the same context and leaves the option as it found it
+    sh = ShardedRBD(rbd)
+    assert torch.equal(sh.rnea_grad(q[:4096], qd[:4096], qdd[:4096]), rbd.rnea_grad(q[:4096], qd[:4096], qdd[:4096]))
+    from rbdreference_amd._lib import RBD_OPT_SELECT_BATCH
+    assert rbd._lib.get_option(RBD_OPT_SELECT_BATCH) == 0
+
+
+@pytest.mark.parametrize("B", [4096, 8192, 8193])
+def test_iiwa_auto_path_at_configs1_and_at_the_selection_boundary(B):
+    """BASELINE configs[1] is iiwa at exactly B = 4 096: the AUTO path (the column kernel there) for rnea, rnea_grad
+    and the one-launch rnea_and_grad against the oracle on 256 sampled rows; and both sides of the batch size at
+    which AUTO switches kernels (8 192 | 8 193 rows for n = 7)."""
+    torch = _torch()
+    from rbdreference_amd import RBDReference
+    from oracle import rbd_oracle as fxo
+    rbd = RBDReference(make_robot("iiwa_like"), build=False)
+    m = fxo.model_from_robot(make_robot("iiwa_like"))
+    rng = np.random.default_rng(B)
+    q = rng.uniform(-np.pi, np.pi, (B, rbd.n)); qd = rng.uniform(-1, 1, (B, rbd.n)); qdd = rng.uniform(-1, 1, (B, rbd.n))
+    tq, tqd, tqdd = (torch.tensor(x, device="cuda:0", dtype=torch.float32) for x in (q, qd, qdd))
+    name = rbd._lib.kernel_name(1, 4, B)
+    assert name.startswith("rnea_grad_cols_kernel") == (B <= 8192), name
+    rows = rng.choice(B, 256, replace=False)
+    c, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    dc = rbd.rnea_grad(tq, tqd, tqdd)
+    c2, v2, a2, f2, dc2 = rbd.rnea_and_grad(tq, tqd, tqdd)
+    cr, vr, ar, fr = fxo.rnea(m, q[rows], qd[rows], qdd[rows])
+    dcr = fxo.rnea_grad(m, q[rows], qd[rows], qdd[rows])
+    for nm, got, want in (("c", c, cr), ("v", v, vr), ("a", a, ar), ("f", f, fr), ("dc_du", dc, dcr),
+                          ("c (one call)", c2, cr), ("v (one call)", v2, vr), ("a (one call)", a2, ar), ("f (one call)", f2, fr),
+                          ("dc_du (one call)", dc2, dcr)):
+        e = rel_err_rows(got[rows].double().cpu().numpy(), want)
+        assert e <= 1e-5, (nm, e)

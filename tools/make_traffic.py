@@ -42,6 +42,13 @@ def main():
                      # SQ_WAVE_CYCLES x 4 / waves shader cycles; a SIMD issues one wave64 VALU instruction per 2 cycles
                      "launch_cycles": c["SQ_WAVE_CYCLES"] * 4.0 / max(waves, 1),
                      "simd_valu_busy_frac": (c["SQ_INSTS_VALU"] * 2.0 / 1024.0) / (c["SQ_WAVE_CYCLES"] * 4.0 / max(waves, 1))}
+        # fp32 flops per launch from the per-opcode-class counters (wave-instructions x 64 lanes; an FMA is two flops)
+        fl = {k: c.get(k) for k in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32")}
+        if fl["SQ_INSTS_VALU_FMA_F32"] is not None:
+            j["valu"].update({k.lower(): v for k, v in fl.items() if v is not None})
+            j["valu"]["flops_per_launch"] = 64.0 * (2.0 * fl["SQ_INSTS_VALU_FMA_F32"] + (fl["SQ_INSTS_VALU_MUL_F32"] or 0.0) +
+                                                    (fl["SQ_INSTS_VALU_ADD_F32"] or 0.0) + (fl["SQ_INSTS_VALU_TRANS_F32"] or 0.0))
+            j["valu"]["flops_per_evaluation"] = j["valu"]["flops_per_launch"] / B
     json.dump(j, open(out, "w"), indent=1)
     print(json.dumps(j, indent=1))
 

@@ -8,13 +8,13 @@ mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python3 bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo bench_rc=$?
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extra > $OUT/bench_prof.json 2> $OUT/bench_prof.err; echo benchprof_rc=$?
 REPS=20 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/configs_stats -- python3 tools/run_configs.py > $OUT/configs.log 2>&1; echo configs_rc=$?
-for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE"; do
+for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d' ' -f1)
   REPS=6 timeout -k 10 120 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_head_$tag -- python3 tools/run_grad.py > $OUT/pmc_head_$tag.log 2>&1 || echo "pmc head $tag failed"
 done
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  REPS=6 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_cfg_$tag -- python3 tools/run_configs.py atlas iiwa4k > $OUT/pmc_cfg_$tag.log 2>&1 || echo "pmc cfg $tag failed"
+  REPS=6 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_cfg_$tag -- python3 tools/run_configs.py atlas iiwa4k quad fb > $OUT/pmc_cfg_$tag.log 2>&1 || echo "pmc cfg $tag failed"
 done
 bash tools/pmc_stalls.sh ${1:-prof}/stalls > $OUT/pmc_stalls.log 2>&1 || echo "pmc stalls failed"
 mkdir -p $OUT/head $OUT/cfg
