@@ -48,6 +48,8 @@ extern "C" {
 #define RBD_ERR_ARG (-1)          /* null / inconsistent arguments                         */
 #define RBD_ERR_UNSUPPORTED (-2)  /* robot too large for this kernel's on-chip working set  */
 #define RBD_ERR_WORKSPACE (-3)    /* workspace missing or too small                        */
+#define RBD_ERR_NOT_BUILT (-4)    /* a FAMILY library (first-use build, rbdreference_amd/build.py) was asked for an entry
+                                     point of another family: the caller picked the wrong library, nothing ran      */
 
 typedef struct rbd_model_info {
   int32_t abi_version;

@@ -116,41 +116,139 @@ def _declare(lib):
 
 
 class RbdLibrary:
-    """A loaded per-robot library, checked against the packed model it is meant to serve."""
+    """The loaded per-robot library, checked against the packed model it is meant to serve.
 
-    def __init__(self, model: PackedModel, build: bool = True):
-        path = lib_path(model)
+    First use of a robot (no up-to-date library on disk, ``build=True``): the full library is built in a background
+    thread while calls are served from small FAMILY libraries built on demand (``build.build_family``: COMMON + the
+    units of one family of entry points in one precision + stubs, 4-15 s each for a 7-DoF robot instead of the
+    whole library's 40 s; minutes for a 30-body robot); as soon as the full library is ready every call goes to it.
+    ``RBD_LAZY_BUILD=0`` (or ``lazy=False``) restores the blocking build.  ``.lib`` is always the FULL library (it
+    waits for the background build if there is one).  Options are process-wide per library file, so they are
+    remembered here and applied to every library of the robot as it is loaded."""
+
+    def __init__(self, model: PackedModel, build: bool = True, lazy=None):
+        import threading
+        from .build import full_library_ready
+        self.model = model
+        self.path = lib_path(model)
+        self._full = None
+        self._fams = {}
+        self._bg = None
+        self._bg_err = None
+        self._opts = {}
+        self._lock = threading.RLock()
+        self._tls = threading.local()
+        if lazy is None:
+            lazy = os.environ.get("RBD_LAZY_BUILD", "1") != "0"
+        if build and lazy and not model.floating and not full_library_ready(model):
+            def work():
+                try:
+                    build_model(model)
+                except BaseException as e:      # noqa: BLE001  (re-raised in the caller's thread by .lib)
+                    self._bg_err = e
+            self._bg = threading.Thread(target=work, name=f"rbd-build-{model.name}", daemon=True)
+            self._bg.start()
+            return
         if build:
-            path = build_model(model)            # no-op when up to date; raises if hipcc is missing
-        if not os.path.exists(path):
+            self.path = build_model(model)            # no-op when up to date; raises if hipcc is missing
+        if not os.path.exists(self.path):
             raise FileNotFoundError(
-                f"HIP library for robot {model.name!r} (hash {model.hash}) not found at {path}; "
+                f"HIP library for robot {model.name!r} (hash {model.hash}) not found at {self.path}; "
                 "build it with rbdreference_amd.build.build_model() -- there is no CPU fallback")
-        self.path = path
-        self.lib = ctypes.CDLL(path)
-        _declare(self.lib)
-        if self.lib.rbd_abi_version() != ABI_VERSION:
-            raise RuntimeError(f"{path}: ABI {self.lib.rbd_abi_version()} != {ABI_VERSION}")
+        self._full = self._load(self.path)
+
+    # ---- loading ------------------------------------------------------------------------------------
+    def _load(self, path: str):
+        model = self.model
+        lib = ctypes.CDLL(path)
+        _declare(lib)
+        if lib.rbd_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI {lib.rbd_abi_version()} != {ABI_VERSION}")
         info = RbdModelInfo()
-        self.check(self.lib.rbd_model_info(ctypes.byref(info)))
+        rc = lib.rbd_model_info(ctypes.byref(info))
+        if rc != 0:
+            raise RbdError(rc, (lib.rbd_last_error() or b"").decode())
         if info.n != model.n or f"{info.hash:016x}" != model.hash or \
                 list(info.parent[:model.n]) != list(model.parent) or info.nv != model.nv or \
                 bool(info.floating_base) != bool(model.floating):
             raise RuntimeError(f"{path}: compiled-in model does not match robot {model.name!r}")
-        self.info = info
+        for o, v in self._opts.items():
+            lib.rbd_set_option(o, v)
+        self._info = info
+        return lib
+
+    def _full_if_ready(self):
+        if self._full is not None:
+            return self._full
+        if self._bg is not None and not self._bg.is_alive():
+            return self.lib
+        return None
+
+    @property
+    def lib(self):
+        """The FULL library (blocks until a background build has finished)."""
+        with self._lock:
+            if self._full is None:
+                if self._bg is not None:
+                    self._bg.join()
+                if self._bg_err is not None:
+                    raise self._bg_err
+                self._full = self._load(self.path)
+            return self._full
+
+    @property
+    def info(self):
+        if getattr(self, "_info", None) is None:
+            self.lib
+        return self._info
+
+    def _family(self, family: str, sfx: str):
+        from .build import build_family, family_lib_path
+        key = (family, sfx)
+        with self._lock:
+            lib = self._fams.get(key)
+            if lib is None:
+                lib = self._load(build_family(self.model, family, sfx))
+                self._fams[key] = lib
+            return lib
+
+    def fn(self, base: str, sfx: str, has_qdd: bool = True):
+        """C entry point ``<base>_<sfx>`` (sfx 'f32' | 'f64'; '' for the suffix-less ones): from the full library when
+        it is ready, else from the family library that serves it (built now if need be)."""
+        from .build import family_of
+        lib = self._full_if_ready()
+        if lib is None:
+            lib = self._family(family_of(base, has_qdd), sfx or "f32")
+        self._tls.lib = lib
+        return getattr(lib, f"{base}_{sfx}" if sfx else base)
 
     def check(self, rc: int):
         if rc != 0:
-            raise RbdError(rc, (self.lib.rbd_last_error() or b"").decode())
+            lib = getattr(self._tls, "lib", None) or self._full_if_ready() or next(iter(self._fams.values()), None) or self.lib
+            raise RbdError(rc, (lib.rbd_last_error() or b"").decode())
+
+    def _loaded(self):
+        return ([self._full] if self._full is not None else []) + list(self._fams.values())
 
     def set_option(self, option: int, value: int) -> None:
-        self.check(self.lib.rbd_set_option(option, value))
+        with self._lock:
+            libs = self._loaded() or [self.lib]
+            for lib in libs:
+                self._tls.lib = lib
+                self.check(lib.rbd_set_option(option, value))
+            self._opts[option] = value
 
     def get_option(self, option: int) -> int:
-        return int(self.lib.rbd_get_option(option))
+        with self._lock:
+            libs = self._loaded() or [self.lib]
+            return int(libs[0].rbd_get_option(option))
 
     def kernel_name(self, op: int, elem_size: int, B: int) -> str:
         """Name of the (dominant) kernel entry point `op` launches for B rows (host-side, no GPU)."""
+        lib = self._full_if_ready()
+        if lib is None:
+            lib = self._family({RBD_OP_RNEA: "rnea", RBD_OP_RNEA_GRAD: "grad", RBD_OP_MINV: "minv"}[op], "f32" if elem_size == 4 else "f64")
+        self._tls.lib = lib
         buf = ctypes.create_string_buffer(128)
-        self.check(self.lib.rbd_kernel_name(op, elem_size, B, buf, len(buf)))
+        self.check(lib.rbd_kernel_name(op, elem_size, B, buf, len(buf)))
         return buf.value.decode()

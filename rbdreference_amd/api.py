@@ -89,6 +89,15 @@ class RBDReference:
             out.append(t.contiguous())
         return out, unb, is_np, dev, dt
 
+    def _minv_ws(self, B: int, esz: int) -> int:
+        """rbd_minv_workspace_bytes from the library that will serve the rbd_minv call of that precision."""
+        lib = self._lib._full_if_ready() or self._lib._family("minv", "f32" if esz == 4 else "f64")
+        return int(lib.rbd_minv_workspace_bytes(B, esz))
+
+    def _fd_ws(self, B: int, esz: int) -> int:
+        lib = self._lib._full_if_ready() or self._lib._family("fd", "f32" if esz == 4 else "f64")
+        return int(lib.rbd_fd_workspace_bytes(B, esz))
+
     @staticmethod
     def _ptr(t: Optional[torch.Tensor]):
         return None if t is None else t.data_ptr()
@@ -106,8 +115,8 @@ class RBDReference:
             raise ValueError(f"out: `{name}` must be a contiguous {dt} tensor of shape {tuple(shape)} on {dev}")
         return t
 
-    def _fn(self, base: str, dt):
-        return getattr(self._lib.lib, f"{base}_{'f32' if dt == torch.float32 else 'f64'}")
+    def _fn(self, base: str, dt, has_qdd: bool = True):
+        return self._lib.fn(base, "f32" if dt == torch.float32 else "f64", has_qdd)
 
     # ------------------------------------------------------------------------------------
     def rnea(self, q, qd, qdd=None, GRAVITY=-9.81, f_ext=None, outputs: str = "cvaf", out=None):
@@ -340,7 +349,7 @@ class RBDReference:
             dc = self._check_out(odc, (B, self.nv, 2 * self.nv), dev, dt, "dc_du")
             c = self._check_out(oc, (B, self.nv), dev, dt, "c") if return_c else None
             with torch.cuda.device(dev):
-                self._lib.check(self._fn("rbd_rnea_grad", dt)(
+                self._lib.check(self._fn("rbd_rnea_grad", dt, qdd is not None)(
                     self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B,
                     self._ptr(c), self._ptr(dc), torch.cuda.current_stream(dev).cuda_stream))
             return (c, dc) if return_c else dc
@@ -348,7 +357,7 @@ class RBDReference:
             dc = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
             c = torch.empty((B, self.nv), device=dev, dtype=dt) if return_c else None
             st = torch.cuda.current_stream(dev).cuda_stream
-            self._lib.check(self._fn("rbd_rnea_grad", dt)(
+            self._lib.check(self._fn("rbd_rnea_grad", dt, qdd is not None)(
                 self._ptr(q), self._ptr(qd), self._ptr(qdd), float(GRAVITY),
                 1 if USE_VELOCITY_DAMPING else 0, B, self._ptr(c), self._ptr(dc), st))
         if return_c:
@@ -387,7 +396,7 @@ class RBDReference:
         with torch.cuda.device(dev):
             M = torch.empty((B, self.nv, self.nv), device=dev, dtype=dt) if out is None else \
                 self._check_out(out, (B, self.nv, self.nv), dev, dt, "Minv")
-            wsb = int(self._lib.lib.rbd_minv_workspace_bytes(B, esz))
+            wsb = self._minv_ws(B, esz)
             if workspace is not None:
                 if workspace.dtype != torch.uint8 or workspace.device != dev or workspace.numel() < wsb or not workspace.is_contiguous():
                     raise ValueError(f"workspace: a contiguous uint8 tensor of >= {wsb} bytes on {dev}")
@@ -401,7 +410,7 @@ class RBDReference:
 
     def minv_workspace_bytes(self, B: int, dtype=torch.float32) -> int:
         """Scratch bytes ``minv`` needs for B rows (0 for robots served by a kernel without workspace)."""
-        return int(self._lib.lib.rbd_minv_workspace_bytes(int(B), 4 if dtype == torch.float32 else 8))
+        return int(self._minv_ws(int(B), 4 if dtype == torch.float32 else 8))
 
     def crba(self, q):
         """RBDReference.crba (fixed-base branch, ``RBDReference.py:1091-1124``) -> joint-space inertia
@@ -435,7 +444,7 @@ class RBDReference:
             qdd = torch.empty((B, self.nv), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
             if not want_grad and self.model.floating:   # rnea (bias force) + minv + one product: scratch for c and Minv
-                wsb = int(self._lib.lib.rbd_fd_workspace_bytes(B, esz))
+                wsb = int(self._fd_ws(B, esz))
                 ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
                 self._lib.check(self._fn("rbd_forward_dynamics", dt)(
                     self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), ws.data_ptr(), wsb, st))
@@ -444,7 +453,7 @@ class RBDReference:
                 self._lib.check(self._fn("rbd_forward_dynamics", dt)(
                     self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), None, 0, st))
                 return qdd, None, unb, is_np
-            wsb = int(self._lib.lib.rbd_fd_workspace_bytes(B, esz))
+            wsb = int(self._fd_ws(B, esz))
             ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
             d = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
             self._lib.check(self._fn("rbd_forward_dynamics_grad", dt)(

@@ -63,7 +63,7 @@ def _sources_digest(m: PackedModel, flags) -> str:
     return h.hexdigest()
 
 
-TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "MINV_F32", "MINV_F64",
+TRANSLATION_UNITS = ["COMMON", "RNEA_F32", "RNEA_F64", "GRAD_F32", "GRAD_F64", "GRADN_F32", "GRADN_F64", "MINV_F32", "MINV_F64",
                      "FD_F32", "FD_F64", "PASS_F32", "PASS_F64"]
 # floating-base robots: COMMON from rbd_kernels.hip + the two units of rbd_fb_kernels.hip
 FB_TRANSLATION_UNITS = ["COMMON", "FB_F32", "FB_F64"]
@@ -94,7 +94,7 @@ class _PrioritySlots:
 
 _HIPCC_SLOTS = _PrioritySlots(max(1, (os.cpu_count() or 2)))
 # relative compile cost of the translation units (measured, 30-body robot), scaled by n^2 per robot
-_TU_COST = {"GRAD_F64": 208, "PASS_F32": 140, "PASS_F64": 125, "GRAD_F32": 114, "MINV_F64": 79, "MINV_F32": 74,
+_TU_COST = {"GRAD_F64": 110, "GRADN_F64": 105, "PASS_F32": 140, "PASS_F64": 125, "GRAD_F32": 60, "GRADN_F32": 57, "MINV_F64": 79, "MINV_F32": 74,
             "RNEA_F64": 50, "RNEA_F32": 47, "FD_F32": 45, "FD_F64": 39, "COMMON": 3}
 
 
@@ -217,6 +217,113 @@ def _build_locked(m, out, flags, digest, force, verbose) -> str:
         f.write(digest + "\n")
     os.replace(stamp_tmp, out + ".stamp")
     return out
+
+
+# ---- first-use builds: one small library per FAMILY of entry points ---------------------------------------------
+# A robot that has never been built blocks its first call for as long as its slowest translation unit takes (the
+# gradient unit of a 30-body robot: minutes), although that call needs one family of kernels in one precision.
+# A family library = COMMON + the units of that family + stubs for every other entry point (they return
+# RBD_ERR_NOT_BUILT), linked and loaded like a full library; rbdreference_amd/_lib.py serves calls from family
+# libraries while the full library builds in the background and switches to it when it is ready.  The gradient
+# family is compiled with -DRBD_FAST_STAGE=1: only the kernel AUTO picks for large batches.
+FAMILIES = {           # family -> units (suffix _F32 / _F64 appended)
+    "rnea": ["RNEA"],
+    "grad": ["GRAD"],                           # rbd_rnea_grad with qdd
+    "gradn": ["GRAD", "GRADN"],                 # ... with qdd = None (:589)
+    "gradr": ["GRAD", "GRADN", "RNEA"],         # rbd_rnea_with_grad: runs the rnea kernel too
+    "minv": ["MINV"],
+    "fd": ["FD", "RNEA", "MINV"],
+    "pass": ["PASS"],
+}
+_FAST_UNITS = {"GRAD", "GRADN", "RNEA"}
+_ALL_FAMILY_UNITS = ["RNEA", "GRAD", "GRADN", "MINV", "FD", "PASS"]
+
+
+def family_of(symbol: str, has_qdd: bool = True) -> str:
+    """Family that serves entry point `symbol` (without the _f32 / _f64 suffix)."""
+    if symbol in ("rbd_rnea", "rbd_rnea_fpass", "rbd_rnea_bpass"):
+        return "rnea"
+    if symbol == "rbd_rnea_grad":
+        return "grad" if has_qdd else "gradn"
+    if symbol == "rbd_rnea_with_grad":
+        return "gradr"
+    if symbol in ("rbd_minv", "rbd_crba", "rbd_minv_workspace_bytes"):
+        return "minv"
+    if symbol in ("rbd_aba", "rbd_forward_dynamics", "rbd_forward_dynamics_grad"):
+        return "fd"
+    return "pass"
+
+
+def family_lib_path(m: PackedModel, family: str, prec: str) -> str:
+    return lib_path(m)[:-3] + f".{family}_{prec}.so"
+
+
+def build_family(m: PackedModel, family: str, prec: str, verbose: bool = False) -> str:
+    """Build (if needed) the family library of packed model `m`: ``family`` in FAMILIES, ``prec`` 'f32' | 'f64'.
+    Fixed-base robots only (a floating-base library is three units: nothing to stage)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import hashlib
+    if m.floating:
+        return build_model(m, verbose=verbose)
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    out = family_lib_path(m, family, prec)
+    flags = list(HIPCC_FLAGS)
+    digest = _sources_digest(m, flags + [family, prec])
+    if _up_to_date(out, digest):
+        return out
+    P = prec.upper()
+    units = [f"{u}_{P}" for u in FAMILIES[family]]
+    missing = [f"{u}_{q}" for u in _ALL_FAMILY_UNITS for q in ("F32", "F64") if f"{u}_{q}" not in units]
+    with _BuildLock(out):
+        if _up_to_date(out, digest):
+            return out
+        uniq = f"{os.getpid()}.{threading.get_ident()}"
+        hdr = header_path(m)
+        hdr_tmp = f"{hdr}.{uniq}.tmp"
+        with open(hdr_tmp, "w") as f:
+            f.write(emit_header(m))
+        os.replace(hdr_tmp, hdr)
+        cache_dir = os.path.join(BUILD_DIR, "objcache")
+        os.makedirs(cache_dir, exist_ok=True)
+        src = os.path.join(CSRC, "rbd_kernels.hip")
+
+        srcs = _sources_digest(m, flags)
+
+        def compile_unit(defs, what, cost):
+            # (keyed by the digest of ALL sources + the unit's defines, not by the preprocessed text as the full build
+            # does: the extra preprocessor run costs 2 s, a fifth of a first-use build)
+            base = [hipcc_path(), *[f for f in flags if f != "-shared"], "-DRBD_TU_SPLIT=1", *defs, "-include", hdr]
+            key = hashlib.sha256((srcs + "\0" + " ".join(defs)).encode()).hexdigest()[:32]
+            obj = os.path.join(cache_dir, f"fam_{key}.o")
+            if os.path.exists(obj):
+                return obj
+            tmp = f"{obj}.{uniq}.{what}.tmp"
+            r = _run([*base, "-c", src, "-o", tmp], f"{m.name} {what}", cost)
+            if verbose and r.stderr:
+                print(r.stderr, file=sys.stderr)
+            os.replace(tmp, obj)
+            return obj
+
+        jobs = [(["-DRBD_TU_COMMON=1"], "COMMON", 3.0),
+                (["-DRBD_TU_STUBS=1", *[f"-DRBD_STUB_{u}=1" for u in missing]], f"STUBS[{family}_{prec}]", 3.0)]
+        for u in units:
+            fast = ["-DRBD_FAST_STAGE=1"] if u.split("_")[0] in _FAST_UNITS else []
+            jobs.append(([f"-DRBD_TU_{u}=1", *fast], u + ("(fast)" if fast else ""), _TU_COST.get(u, 50) * m.n * m.n))
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            objs = list(ex.map(lambda j: compile_unit(*j), jobs))
+        link_tmp = f"{out}.{uniq}.tmp"
+        _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", link_tmp], f"{m.name} {family}_{prec} link", 2e9)
+        os.replace(link_tmp, out)
+        stamp_tmp = f"{out}.stamp.{uniq}.tmp"
+        with open(stamp_tmp, "w") as f:
+            f.write(digest + "\n")
+        os.replace(stamp_tmp, out + ".stamp")
+    return out
+
+
+def full_library_ready(m: PackedModel) -> bool:
+    """True when the full library of `m` exists and was built from the current sources."""
+    return _up_to_date(lib_path(m), _sources_digest(m, list(HIPCC_FLAGS)))
 
 
 def build_models_parallel(models, force: bool = False, jobs: Optional[int] = None) -> list:

@@ -9,6 +9,7 @@
 #include "rbd_fb.h"
 #include "rbd_fb_world.h"
 #include "rbd_fb_passes.h"
+#include "rbd_fb_minv.h"
 #include "../../include/rbd_hip.h"
 #include <cstdio>
 #include <cstring>
@@ -140,6 +141,20 @@ int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
   if (B == 0) return 0;
   if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
   if (misaligned(Minv)) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be 16-byte aligned");
+  if constexpr (minv_fbm_ok<T>()) {
+    // one wave per subtree of the base (rbd_fb_minv.h); RBD_OPT_MINV_PHASE_A = LANE keeps the four-lanes kernel
+    if (rbd_option(RBD_OPT_MINV_PHASE_A) != RBD_MINV_PHASE_A_LANE) {
+      const int64_t nb = (B + 63) / 64;
+      if (nb > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
+      constexpr size_t ldsm = minv_fbm_lds_bytes<T>();
+      auto km = minv_fbm_kernel<T>;
+      int rcm;
+      if ((rcm = ensure_lds(km, ldsm)) != 0) return rcm;
+      hipLaunchKernelGGL(km, dim3((unsigned)nb), dim3(64 * FBW_W), ldsm, (hipStream_t)stream, q, (long long)B, dense, Minv);
+      hipError_t em = hipGetLastError();
+      return em == hipSuccess ? 0 : hip_fail(em, "rbd_minv (floating base, wave per subtree) launch");
+    }
+  }
   const int64_t blocks = (B + 64 / FB_MINV_L - 1) / (64 / FB_MINV_L);
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   constexpr size_t lds = minv_fb_lds_bytes<T>();
@@ -330,7 +345,11 @@ __attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f64(void);
     std::snprintf(buf, len, "%s<%s,true>", rbdk::rnea_fbw_lds_bytes<T>() <= 160 * 1024 ? "rnea_fbw_kernel" : "rnea_fb_kernel", sizeof(T) == 4 ? "float" : "double"); \
     return 0;                                                                                                               \
   }                                                                                                                         \
-  int rbd_minv_kernel_name_##SFX(int64_t, char* buf, size_t len) { std::snprintf(buf, len, "minv_fb_kernel<%s>", sizeof(T) == 4 ? "float" : "double"); return 0; } \
+  int rbd_minv_kernel_name_##SFX(int64_t, char* buf, size_t len) {                                                          \
+    const bool m = rbdk::minv_fbm_ok<T>() && rbd_option(RBD_OPT_MINV_PHASE_A) != RBD_MINV_PHASE_A_LANE;                      \
+    std::snprintf(buf, len, "%s<%s>", m ? "minv_fbm_kernel" : "minv_fb_kernel", sizeof(T) == 4 ? "float" : "double");      \
+    return 0;                                                                                                               \
+  }                                                                                                                         \
   int rbd_rnea_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {   \
     return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \
   }                                                                                                                         \

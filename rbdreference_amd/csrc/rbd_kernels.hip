@@ -24,14 +24,23 @@
 //   crba, rnea_fpass / rnea_bpass, forward_dynamics(_grad): further rows, same building blocks.
 // The library is built from several translation units of this one file (rbdreference_amd/build.py
 // compiles them in parallel): -DRBD_TU_COMMON, _RNEA_F32, _RNEA_F64, _GRAD_F32, _GRAD_F64,
-// _MINV_F32, _MINV_F64, _FD_F32, _FD_F64, _PASS_F32, _PASS_F64 (each together with -DRBD_TU_SPLIT);
+// _GRADN_F32, _GRADN_F64 (the qdd = None instantiations of the gradient kernels: half of a gradient unit's compile
+// time), _MINV_F32, _MINV_F64, _FD_F32, _FD_F64, _PASS_F32, _PASS_F64 (each together with -DRBD_TU_SPLIT);
 // without RBD_TU_SPLIT everything is compiled in one unit.
+// -DRBD_FAST_STAGE=1 (first-use family libraries of the gradient, rbdreference_amd/build.py): only the kernel AUTO
+// picks for large batches is compiled -- no small-batch column kernel, no kernels that exist to be forced by
+// rbd_set_option -- which cuts the unit's compile time to a third; the full library replaces it when it is ready.
+#ifndef RBD_FAST_STAGE
+#define RBD_FAST_STAGE 0
+#endif
 #if !defined(RBD_TU_SPLIT)
 #define RBD_TU_COMMON 1
 #define RBD_TU_RNEA_F32 1
 #define RBD_TU_RNEA_F64 1
 #define RBD_TU_GRAD_F32 1
 #define RBD_TU_GRAD_F64 1
+#define RBD_TU_GRADN_F32 1
+#define RBD_TU_GRADN_F64 1
 #define RBD_TU_MINV_F32 1
 #define RBD_TU_MINV_F64 1
 #define RBD_TU_FD_F32 1
@@ -45,7 +54,8 @@
 #if defined(RBD_TU_RNEA_F32) || defined(RBD_TU_RNEA_F64)
 #define RBD_NEED_RNEA 1
 #endif
-#if defined(RBD_TU_GRAD_F32) || defined(RBD_TU_GRAD_F64) || defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
+#if defined(RBD_TU_GRAD_F32) || defined(RBD_TU_GRAD_F64) || defined(RBD_TU_GRADN_F32) || defined(RBD_TU_GRADN_F64) || \
+    defined(RBD_TU_FD_F32) || defined(RBD_TU_FD_F64)
 #define RBD_NEED_GRAD 1
 #endif
 #if defined(RBD_TU_MINV_F32) || defined(RBD_TU_MINV_F64)
@@ -1929,6 +1939,11 @@ static inline int64_t rbd_select_batch(int64_t B) {
 // points instead of instantiating the same templates a second time (Atlas: the fp64 gradient kernel
 // alone costs 200 s of compile time).  rbd_minv_fd_* = rbd_minv_* plus the fused qdd = Minv (u - c).
 extern "C" {
+// qdd = None gradient launches (GRADN units) for the GRAD / FD units
+__attribute__((visibility("hidden"))) int rbd_grad_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* dc_du, void* stream);
+__attribute__((visibility("hidden"))) int rbd_grad_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* dc_du, void* stream);
+__attribute__((visibility("hidden"))) int rbd_grad_cols_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* v, float* a, float* f, float* dc_du, void* stream);
+__attribute__((visibility("hidden"))) int rbd_grad_cols_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* v, double* a, double* f, double* dc_du, void* stream);
 __attribute__((visibility("hidden"))) int rbd_minv_fd_f32(const float* q, int64_t B, float* Minv, void* workspace, size_t wsb,
                                                           void* stream, const float* u, const float* c, float* qdd);
 __attribute__((visibility("hidden"))) int rbd_minv_fd_f64(const double* q, int64_t B, double* Minv, void* workspace, size_t wsb,
@@ -2033,7 +2048,7 @@ int rnea_launch(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* 
       return 0;
     }
   }
-  if constexpr (rnea_groups_ok<T>()) {
+  if constexpr (rnea_groups_ok<T>() && !(RBD_FAST_STAGE && rnea_segs_ok<T>())) {   // (first-use build: not next to the segment kernel AUTO picks)
     // one wave per independent root group: faster than one lane per configuration at every batch size
     // measured (Atlas fp32: 17.4 -> 13.5 us at B = 16 384, 235 -> 167 us at B = 262 144; quadruped fp32
     // B = 1M: 199 -> 174 us = 6.4 TB/s)
@@ -2156,8 +2171,9 @@ int idsva_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_dampi
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
     return 0;
-  }
+  } else
 #endif
+  {   // (an else branch: the kernel below is not even instantiated where the pipelined one serves the robot)
   auto k = rnea_grad_idsva_kernel<T, HAS_QDD, FDG>;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;
   if ((rc = resident_blocks(k, 64, lds, &resident)) != 0) return rc;
@@ -2173,6 +2189,7 @@ int idsva_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_dampi
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
   return 0;
+  }
 }
 
 // Small batches: one lane per (configuration, derivative column) (rbd_grad_cols.h).  Chosen when the
@@ -2181,7 +2198,7 @@ constexpr int64_t GRAD_COLS_MAX_WAVES = 2048;
 template <class T>
 inline bool grad_use_cols(int64_t B) {
   using namespace rbdk;
-  if (!grad_cols_ok<T>()) return false;
+  if (RBD_FAST_STAGE || !grad_cols_ok<T>()) return false;
   const int opt = rbd_option(RBD_OPT_GRAD_KERNEL);
   if (opt == RBD_GRAD_KERNEL_COLS) return true;
   if (opt != RBD_GRAD_KERNEL_AUTO) return false;
@@ -2191,7 +2208,7 @@ template <class T, bool HAS_QDD>
 int grad_cols_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
                      T* c, T* v, T* a, T* f, T* dc_du, void* stream) {
   using namespace rbdk;
-  if constexpr (!grad_cols_ok<T>()) {
+  if constexpr (RBD_FAST_STAGE || !grad_cols_ok<T>()) {
     return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: the column kernel is not built for this robot size");
   } else {
     const int64_t blocks = (B + GC_CPW - 1) / GC_CPW;
@@ -2213,7 +2230,7 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
   // fp32 robots whose default is the tree kernel never build the column kernel (Atlas: 404 VGPRs of
   // code nobody runs); fp64 x big tree would need > 512 VGPRs and is not built either.
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
-  constexpr bool TREE_BUILT = GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
+  constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
   if constexpr (TREE_BUILT) {
     constexpr size_t lds = tree_lds_bytes<T>();
     static_assert(!TREE_ONLY || lds <= 160 * 1024, "tree kernel is the only gradient kernel of this robot but does not fit LDS");
@@ -2249,7 +2266,9 @@ int rnea_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   if (((reinterpret_cast<uintptr_t>(dc_du) | reinterpret_cast<uintptr_t>(c)) & 15u) != 0)
     return fail(RBD_ERR_ARG, "rbd_rnea_grad: output buffers must be 16-byte aligned");
   if (qdd) return rnea_grad_launch_q<T, true>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
-  return rnea_grad_launch_q<T, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+  // qdd = None (:589): the HAS_QDD = false kernels live in the GRADN unit
+  if constexpr (sizeof(T) == 4) return rbd_grad_noqdd_f32((const float*)q, (const float*)qd, (float)gravity, use_damping, B, (float*)c, (float*)dc_du, stream);
+  else return rbd_grad_noqdd_f64((const double*)q, (const double*)qd, (double)gravity, use_damping, B, (double*)c, (double*)dc_du, stream);
 }
 
 // rnea + rnea_grad: (c, v, a, f, dc_du).  One launch when the column kernel serves the batch, otherwise the
@@ -2265,7 +2284,8 @@ int rnea_with_grad_launch(const T* q, const T* qd, const T* qdd, T gravity, int 
     return fail(RBD_ERR_ARG, "rbd_rnea_with_grad: output buffers must be 16-byte aligned");
   if (grad_use_cols<T>(B)) {
     if (qdd) return grad_cols_launch<T, true>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
-    return grad_cols_launch<T, false>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+    if constexpr (sizeof(T) == 4) return rbd_grad_cols_noqdd_f32((const float*)q, (const float*)qd, (float)gravity, use_damping, B, (float*)c, (float*)v, (float*)a, (float*)f, (float*)dc_du, stream);
+    else return rbd_grad_cols_noqdd_f64((const double*)q, (const double*)qd, (double)gravity, use_damping, B, (double*)c, (double*)v, (double*)a, (double*)f, (double*)dc_du, stream);
   }
   int rc;
   if constexpr (sizeof(T) == 4) rc = rbd_rnea_f32((const float*)q, (const float*)qd, (const float*)qdd, (float)gravity, B, (float*)c, (float*)v, (float*)a, (float*)f, stream);
@@ -2281,7 +2301,7 @@ int grad_kernel_name(int64_t B, char* buf, size_t len) {
   const char* t = sizeof(T) == 4 ? "float" : "double";
   if (grad_use_cols<T>(B)) { std::snprintf(buf, len, "rnea_grad_cols_kernel<%s,true>", t); return 0; }
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
-  constexpr bool TREE_BUILT = GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
+  constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
   bool tree = TREE_ONLY;
   if constexpr (TREE_BUILT) tree = tree || (rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE && tree_lds_bytes<T>() <= 160 * 1024);
   if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);
@@ -2704,6 +2724,22 @@ int rbd_rnea_f64(const double* q, const double* qd, const double* qdd, double gr
   return rnea_launch<double>(q, qd, qdd, gravity, B, c, v, a, f, stream);
 }
 #endif
+#ifdef RBD_TU_GRADN_F32
+int rbd_grad_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* dc_du, void* stream) {
+  return rnea_grad_launch_q<float, false>(q, qd, nullptr, gravity, use_damping, B, c, dc_du, stream);
+}
+int rbd_grad_cols_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* v, float* a, float* f, float* dc_du, void* stream) {
+  return grad_cols_launch<float, false>(q, qd, nullptr, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+}
+#endif
+#ifdef RBD_TU_GRADN_F64
+int rbd_grad_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* dc_du, void* stream) {
+  return rnea_grad_launch_q<double, false>(q, qd, nullptr, gravity, use_damping, B, c, dc_du, stream);
+}
+int rbd_grad_cols_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* v, double* a, double* f, double* dc_du, void* stream) {
+  return grad_cols_launch<double, false>(q, qd, nullptr, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+}
+#endif
 #ifdef RBD_TU_GRAD_F32
 int rbd_rnea_grad_f32(const float* q, const float* qd, const float* qdd, float gravity,
                       int use_damping, int64_t B, float* c, float* dc_du, void* stream) {
@@ -2823,5 +2859,76 @@ int rbd_minv_fpass_f64(const double* q, int64_t B, double* Minv, double* F, cons
   return minv_fpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
 }
 #endif
+
+// ---- stubs (-DRBD_TU_STUBS with -DRBD_STUB_<unit> per missing unit): a FAMILY library holds COMMON, the units of one
+// family and these, so that it links and loads like a full library; an entry point of another family says so ------
+#ifdef RBD_TU_STUBS
+#define RBD_STUB_BODY(name) { return fail(RBD_ERR_NOT_BUILT, name ": not part of this family library (rbdreference_amd.build: first-use build)"); }
+#define RBD_STUBS_RNEA(SFX, T)                                                                                                   \
+  int rbd_rnea_kernel_name_##SFX(int64_t, char*, size_t) RBD_STUB_BODY("rbd_kernel_name(RBD_OP_RNEA)")                           \
+  int rbd_rnea_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, T*, T*, void*) RBD_STUB_BODY("rbd_rnea")                  \
+  int rbd_rnea_fpass_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_fpass")          \
+  int rbd_rnea_bpass_##SFX(const T*, T*, int64_t, T*, void*) RBD_STUB_BODY("rbd_rnea_bpass")
+#define RBD_STUBS_GRAD(SFX, T)                                                                                                   \
+  int rbd_grad_kernel_name_##SFX(int64_t, char*, size_t) RBD_STUB_BODY("rbd_kernel_name(RBD_OP_RNEA_GRAD)")                      \
+  int rbd_rnea_grad_##SFX(const T*, const T*, const T*, T, int, int64_t, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_grad")           \
+  int rbd_rnea_with_grad_##SFX(const T*, const T*, const T*, T, int, int64_t, T*, T*, T*, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_with_grad")
+#define RBD_STUBS_GRADN(SFX, T)                                                                                                  \
+  int rbd_grad_noqdd_##SFX(const T*, const T*, T, int, int64_t, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_grad (qdd = NULL)")      \
+  int rbd_grad_cols_noqdd_##SFX(const T*, const T*, T, int, int64_t, T*, T*, T*, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_with_grad (qdd = NULL)")
+#define RBD_STUBS_MINV(SFX, T)                                                                                                   \
+  int rbd_minv_kernel_name_##SFX(int64_t, char*, size_t) RBD_STUB_BODY("rbd_kernel_name(RBD_OP_MINV)")                           \
+  int rbd_minv_needs_ws_##SFX(void) { return 1; }                                                                                \
+  int rbd_crba_##SFX(const T*, int64_t, T*, void*) RBD_STUB_BODY("rbd_crba")                                                     \
+  int rbd_minv_##SFX(const T*, int64_t, int, T*, void*, size_t, void*) RBD_STUB_BODY("rbd_minv")                                 \
+  int rbd_minv_fd_##SFX(const T*, int64_t, T*, void*, size_t, void*, const T*, const T*, T*) RBD_STUB_BODY("rbd_minv")
+#define RBD_STUBS_FD(SFX, T)                                                                                                     \
+  int rbd_aba_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*) RBD_STUB_BODY("rbd_aba")                                \
+  int rbd_forward_dynamics_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*, size_t, void*) RBD_STUB_BODY("rbd_forward_dynamics") \
+  int rbd_forward_dynamics_grad_##SFX(const T*, const T*, const T*, T, int64_t, T*, T*, void*, size_t, void*) RBD_STUB_BODY("rbd_forward_dynamics_grad")
+#define RBD_STUBS_PASS(SFX, T)                                                                                                   \
+  int rbd_rnea_grad_fpass_dq_##SFX(const T*, const T*, const T*, const T*, T, int64_t, T*, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_grad_fpass_dq") \
+  int rbd_rnea_grad_fpass_dqd_##SFX(const T*, const T*, const T*, int64_t, T*, T*, T*, void*) RBD_STUB_BODY("rbd_rnea_grad_fpass_dqd") \
+  int rbd_rnea_grad_bpass_dq_##SFX(const T*, const T*, T*, int64_t, T*, void*) RBD_STUB_BODY("rbd_rnea_grad_bpass_dq")           \
+  int rbd_rnea_grad_bpass_dqd_##SFX(const T*, T*, int, int64_t, T*, void*) RBD_STUB_BODY("rbd_rnea_grad_bpass_dqd")              \
+  int rbd_minv_bpass_##SFX(const T*, int64_t, T*, T*, T*, T*, void*) RBD_STUB_BODY("rbd_minv_bpass")                             \
+  int rbd_minv_fpass_##SFX(const T*, int64_t, T*, T*, const T*, const T*, void*) RBD_STUB_BODY("rbd_minv_fpass")
+#ifdef RBD_STUB_RNEA_F32
+RBD_STUBS_RNEA(f32, float)
+#endif
+#ifdef RBD_STUB_RNEA_F64
+RBD_STUBS_RNEA(f64, double)
+#endif
+#ifdef RBD_STUB_GRAD_F32
+RBD_STUBS_GRAD(f32, float)
+#endif
+#ifdef RBD_STUB_GRAD_F64
+RBD_STUBS_GRAD(f64, double)
+#endif
+#ifdef RBD_STUB_GRADN_F32
+RBD_STUBS_GRADN(f32, float)
+#endif
+#ifdef RBD_STUB_GRADN_F64
+RBD_STUBS_GRADN(f64, double)
+#endif
+#ifdef RBD_STUB_MINV_F32
+RBD_STUBS_MINV(f32, float)
+#endif
+#ifdef RBD_STUB_MINV_F64
+RBD_STUBS_MINV(f64, double)
+#endif
+#ifdef RBD_STUB_FD_F32
+RBD_STUBS_FD(f32, float)
+#endif
+#ifdef RBD_STUB_FD_F64
+RBD_STUBS_FD(f64, double)
+#endif
+#ifdef RBD_STUB_PASS_F32
+RBD_STUBS_PASS(f32, float)
+#endif
+#ifdef RBD_STUB_PASS_F64
+RBD_STUBS_PASS(f64, double)
+#endif
+#endif  // RBD_TU_STUBS
 
 }  // extern "C"

@@ -339,3 +339,30 @@ def test_fb_full_size_sampled_rows(dtname):
     back = torch.einsum("bij,bj->bi", Mi.double(), (c - c0).double())
     err = (back - tqdd.double()).abs().amax(1) / tqdd.double().abs().amax(1)
     assert float(err.max()) <= (1e-9 if dt == torch.float64 else 2e-2), float(err.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", fb_golden_names())
+def test_fb_both_minv_kernels_vs_golden(name):
+    """minv on the wave-per-subtree kernel (AUTO, rbd_fb_minv.h) and on the four-lanes kernel (RBD_MINV_PHASE_A_LANE),
+    dense and upper, both precisions, and a ragged batch that ends inside a 16-configuration output image."""
+    import torch
+    from rbdreference_amd._lib import RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_OPT_MINV_PHASE_A
+    g = load_golden(name); rbd = _rbd(name); m = fbo.model_from_robot(make_robot(name))
+    rng = np.random.default_rng(3)
+    qr = rng.uniform(-np.pi, np.pi, (83, m.n))
+    Mr = fbo.minv(m, qr)
+    try:
+        for opt, want in ((RBD_MINV_PHASE_A_AUTO, "minv_fbm_kernel"), (RBD_MINV_PHASE_A_LANE, "minv_fb_kernel")):
+            rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, opt)
+            for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
+                assert rbd._lib.kernel_name(2, 8 if dt == torch.float64 else 4, 8).startswith(want)
+                q = torch.tensor(g["q"], device="cuda:0", dtype=dt)
+                Mi = rbd.minv(q)
+                assert rel_err_rows(Mi.double().cpu().numpy(), g["Minv_dense"]) <= tol, (want, dt)
+                assert torch.equal(Mi, Mi.transpose(1, 2))
+                assert rel_err_rows(rbd.minv(q, output_dense=False).double().cpu().numpy(), np.triu(g["Minv_upper"])) <= tol
+                e = rel_err_rows(rbd.minv(torch.tensor(qr, device="cuda:0", dtype=dt)).double().cpu().numpy(), Mr)
+                assert e <= tol, (want, dt, "ragged", e)
+    finally:
+        rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, RBD_MINV_PHASE_A_AUTO)

@@ -193,3 +193,68 @@ def test_robot_name_cannot_inject_code_into_the_generated_header():
     assert all(ch.isalnum() or ch in "_." for ch in os.path.basename(lib_path(m)))
     assert len(safe_name("a" * 200)) == 63 and safe_name("") == "robot"
     assert pack_robot(iiwa_like(), evil).hash == pack_robot(iiwa_like()).hash      # the name is not part of the model
+
+
+def _fresh_robot(name, parents, seed):
+    """A robot whose libraries do not exist yet: whatever an earlier run left behind is removed first."""
+    import glob
+    from rbdreference_amd.build import lib_path
+    from rbdreference_amd.packer import pack_robot
+    from rbdreference_amd.robot import random_tree
+    m = pack_robot(random_tree(parents, seed=seed, name=name))
+    for f in glob.glob(lib_path(m)[:-3] + "*"):
+        os.remove(f)
+    return m
+
+
+def test_first_use_family_library_builds_within_its_bound_and_says_what_it_lacks():
+    """a robot that has never been built answers its first call from a FAMILY library (COMMON + one
+    family of entry points + stubs) instead of waiting for the whole library.  No GPU here: the bound is on the build
+    (hipcc cross-compiles), the library must load, carry the robot, export every symbol of the header, and a stub
+    must say RBD_ERR_NOT_BUILT.  Measured on the 8-core build container: rnea 4-9 s, gradient 10-16 s for 7 bodies
+    (the whole library: 40 s); the bounds below leave room for a loaded machine."""
+    import ctypes
+    import time
+    from rbdreference_amd._lib import EXPORTED_SYMBOLS, RbdModelInfo, _declare
+    from rbdreference_amd.build import build_family, family_lib_path, full_library_ready
+    m = _fresh_robot("first_use_probe_chain7", [-1, 0, 1, 2, 3, 4, 5], 4242)
+    assert not full_library_ready(m)
+    t0 = time.time()
+    p = build_family(m, "rnea", "f32")
+    t_rnea = time.time() - t0
+    t0 = time.time()
+    pg = build_family(m, "grad", "f32")
+    t_grad = time.time() - t0
+    assert p == family_lib_path(m, "rnea", "f32") and os.path.exists(p) and os.path.exists(pg)
+    assert t_rnea <= 40.0 and t_grad <= 45.0, (t_rnea, t_grad)
+    lib = ctypes.CDLL(pg)
+    _declare(lib)
+    for sym in EXPORTED_SYMBOLS:
+        assert hasattr(lib, sym), sym
+    info = RbdModelInfo()
+    assert lib.rbd_model_info(ctypes.byref(info)) == 0 and f"{info.hash:016x}" == m.hash and info.n == 7
+    rc = lib.rbd_minv_f32(None, 4, 1, None, None, 0, None)              # another family's entry point: a stub
+    assert rc == -4 and b"not part of this family library" in lib.rbd_last_error()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.rbd_kernel_name(1, 4, 1 << 20, buf, len(buf)) == 0 and buf.value.startswith(b"rnea_grad_")
+    t0 = time.time()
+    assert build_family(m, "grad", "f32") == pg and time.time() - t0 < 2.0    # up to date: no compiler run
+
+
+def test_lazy_library_serves_families_first_and_the_full_library_when_it_is_ready():
+    """RbdLibrary on a never-built robot returns at once, hands out entry points from family libraries while the full
+    library builds in the background, and `.lib` (the full library) waits for that build."""
+    import time
+    from rbdreference_amd._lib import RBD_OPT_GRAD_KERNEL, RbdLibrary
+    from rbdreference_amd.build import full_library_ready
+    m = _fresh_robot("first_use_probe_n2", [-1, 0], 4243)
+    t0 = time.time()
+    L = RbdLibrary(m, build=True, lazy=True)
+    assert time.time() - t0 < 2.0 and L._full is None and L._bg is not None
+    f = L.fn("rbd_rnea", "f32")
+    assert f is not None and (("rnea", "f32") in L._fams or L._full is not None)
+    L.set_option(RBD_OPT_GRAD_KERNEL, 3)                                  # remembered, and applied to libraries loaded later
+    full = L.lib                                                          # blocks until the background build is done
+    assert full_library_ready(m) and full.rbd_get_option(RBD_OPT_GRAD_KERNEL) == 3
+    assert L.fn("rbd_rnea", "f32") is not None and L._tls.lib is full
+    assert L.info.n == 2
