@@ -1,8 +1,8 @@
 // rbd_crba.h -- crba(q): joint-space inertia matrix H [B, n, n]  (RBDReference.py:1091-1124, fixed base).
 // SURVEY.md §8f-4 "next" row; the golden files already hold the reference's H (it is the Minv H = I
-// witness).  One configuration per lane: composite inertias IC_p += X^T IC X from the leaves up
-// (:1096-1103), then for every body fh = IC_i S_i is carried up its root path, H[i, j] = S_j^T fh
-// (:1107-1122).  Rows are staged per group (root subtree) in LDS and streamed out coalesced; robots
+// witness).  One configuration per lane, one sweep from the leaves up: a body's composite inertia is final when the
+// sweep reaches it (IC_p += X^T IC X, :1096-1103), fh = IC_i S_i is carried up its root path right then,
+// H[i, j] = S_j^T fh (:1107-1122), and the composite moves on to the parent.  Rows are staged per group (root subtree) in LDS and streamed out coalesced; robots
 // whose largest group tile exceeds LDS write H with per-lane strided stores instead.
 #pragma once
 #include "rbd_spatial.h"
@@ -45,9 +45,37 @@ __global__ __launch_bounds__(64) void crba_kernel(const T* __restrict__ q, long 
         });
       });
     });
+    // One descending sweep: when body i is reached every child has added its composite, so IC_i is final --
+    // fh = IC_i S_i climbs the root path NOW (:1107-1122) and IC_i is handed to the parent and dies (:1096-1103).
+    // (Two separate sweeps keep the composite of every body of the group alive between them: 36 n values, scratch
+    // for 18 bodies in fp64.)
+    const bool ok = TILE || lane < nvalid;
     sfor_down<row0, row0 + rows>([&](auto I) {
       constexpr int i = decltype(I)::value;
       constexpr int p = PARENT[i];
+      constexpr int si = s_index(i);
+      {
+        T fh[6];
+        sfor<0, 6>([&](auto R) { fh[decltype(R)::value] = IC[i][decltype(R)::value][si]; });   // IC_i S_i
+        if (ok) my[i * N + i] = fh[si];
+        // structural zeros: bodies of this group that are unrelated to i, and every other group
+        sfor<0, N>([&](auto C) {
+          constexpr int c = decltype(C)::value;
+          if constexpr (!related(i, c)) { if (ok) my[i * N + c] = T(0); }
+        });
+        // climb the root path
+        sfor_down<row0, i + 1>([&](auto JJ) {
+          constexpr int jj = decltype(JJ)::value;           // ancestors-or-self of i, in descending index order
+          if constexpr (is_anc_or_self(jj, i) && PARENT[jj] >= 0) {
+            constexpr int pj = PARENT[jj];
+            T y[6];
+            xform_T<jj>(tr[jj], fh, y);
+            sfor<0, 6>([&](auto R) { fh[decltype(R)::value] = y[decltype(R)::value]; });
+            const T h = S_dot<pj>(fh);
+            if (ok) { my[i * N + pj] = h; my[pj * N + i] = h; }
+          }
+        });
+      }
       if constexpr (p >= 0) {
         T A[6][6];   // A = X^T IC
         sfor<0, 6>([&](auto C) {
@@ -64,32 +92,6 @@ __global__ __launch_bounds__(64) void crba_kernel(const T* __restrict__ q, long 
           sfor<0, 6>([&](auto C) { IC[p][r][decltype(C)::value] += y[decltype(C)::value]; });
         });
       }
-    });
-    // H rows / columns (:1107-1122)
-    const bool ok = TILE || lane < nvalid;
-    sfor<row0, row0 + rows>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int si = s_index(i);
-      T fh[6];
-      sfor<0, 6>([&](auto R) { fh[decltype(R)::value] = IC[i][decltype(R)::value][si]; });   // IC_i S_i
-      if (ok) my[i * N + i] = fh[si];
-      // structural zeros: bodies of this group that are unrelated to i, and every other group
-      sfor<0, N>([&](auto C) {
-        constexpr int c = decltype(C)::value;
-        if constexpr (!related(i, c)) { if (ok) my[i * N + c] = T(0); }
-      });
-      // climb the root path
-      sfor_down<row0, i + 1>([&](auto JJ) {
-        constexpr int jj = decltype(JJ)::value;           // ancestors-or-self of i, in descending index order
-        if constexpr (is_anc_or_self(jj, i) && PARENT[jj] >= 0) {
-          constexpr int pj = PARENT[jj];
-          T y[6];
-          xform_T<jj>(tr[jj], fh, y);
-          sfor<0, 6>([&](auto R) { fh[decltype(R)::value] = y[decltype(R)::value]; });
-          const T h = S_dot<pj>(fh);
-          if (ok) { my[i * N + pj] = h; my[pj * N + i] = h; }
-        }
-      });
     });
     if constexpr (TILE) {
       __syncthreads();

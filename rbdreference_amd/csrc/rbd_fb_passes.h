@@ -14,6 +14,10 @@
 namespace rbdk {
 
 constexpr int FBP_L = 8;                 // lanes per configuration (they share the columns)
+constexpr int fbp_child_root(int j) {     // the child of the base that body j >= 1 hangs under
+  while (PARENT[j] != 0) j = PARENT[j];
+  return j;
+}
 constexpr int FBP_C = 64 / FBP_L;        // configurations per block
 
 // ---- rnea_grad forward passes: column `col` of (dv, da, df) for every body -----------------------------------
@@ -32,9 +36,10 @@ __global__ __launch_bounds__(64, 1) void fb_grad_fpass_kernel(const T* __restric
   const T* ab = ISQD ? nullptr : a_in + b * (6 * N);
   JTrig<T> tr[N];
   T qdv[N];
-  T v[N][6];
   sfor<1, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qb[j + 5]); qdv[j] = qdb[j + 5]; });
-  sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; v[j][r] = vb[r * N + j]; }); });
+  // v [6][NB] of the configuration is an INPUT: read where it is used (every column re-reads it from L1 / L2) instead
+  // of living in 6 NB registers next to the column's dv and da (fp64: 512 VGPRs and scratch otherwise)
+  auto vload = [&](int j, T (&x)[6]) { sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; x[r] = vb[r * N + j]; }); };
   T qd0[6];
   sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; qd0[r] = qdb[r]; });
   T ag0[6];                                             // X_0 a_grav
@@ -48,7 +53,6 @@ __global__ __launch_bounds__(64, 1) void fb_grad_fpass_kernel(const T* __restric
 #pragma clang loop unroll(disable)
   for (int col = sub; col < NV; col += FBP_L) {
     sfor<1, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j].s = launder(tr[j].s); tr[j].c = launder(tr[j].c); });
-    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; v[j][r] = launder(v[j][r]); }); });
     T dv[N][6], da[N][6];
     auto emit = [&](auto I, const T (&d)[6]) {
       constexpr int i = decltype(I)::value;
@@ -64,21 +68,22 @@ __global__ __launch_bounds__(64, 1) void fb_grad_fpass_kernel(const T* __restric
       // da = crm(dv) qd[0:6] (:1236-1238) + crm(v_0) e_col (:1243)
       T e[6];
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; e[r] = col == r ? T(1) : T(0); });
-      T t0[6], t1[6], t2[6];
+      T t0[6], t1[6], t2[6], v0[6];
+      vload(0, v0);
       crm_mul(ag0, e, t0);
       crm_mul(e, qd0, t1);
-      crm_mul(v[0], e, t2);
+      crm_mul(v0, e, t2);
       sfor<0, 6>([&](auto R) {
         constexpr int r = decltype(R)::value;
         dv[0][r] = ISQD ? e[r] : T(0);
         da[0][r] = ISQD ? t1[r] + t2[r] : t0[r];
       });
       T Iv[6], Idv[6], d[6];
-      cmatvec<MatI, 0>(v[0], Iv);
+      cmatvec<MatI, 0>(v0, Iv);
       cmatvec<MatI, 0>(dv[0], Idv);
       cmatvec<MatI, 0>(da[0], d);
       fxv<true>(dv[0], Iv, d);
-      fxv<true>(v[0], Idv, d);
+      fxv<true>(v0, Idv, d);
       emit(std::integral_constant<int, 0>{}, d);
     }
     sfor<1, N>([&](auto I) {
@@ -87,8 +92,9 @@ __global__ __launch_bounds__(64, 1) void fb_grad_fpass_kernel(const T* __restric
       const bool own = col == i + 5;
       xform<i>(tr[i], dv[p], dv[i]);          // (:1158 / :1230)
       xform<i>(tr[i], da[p], da[i]);          // (:1163 / :1234)
-      T xv[6], sdq[6], sS[6], e1[6], e2[6];
-      xform<i>(tr[i], v[p], xv);
+      T xv[6], sdq[6], sS[6], e1[6], e2[6], vp[6], vi[6];
+      vload(p, vp); vload(i, vi);
+      xform<i>(tr[i], vp, xv);
       mxS<i>(xv, T(1), sdq);                  // crm(X v_p) S   (:1159)
       sfor<0, 6>([&](auto R) { sS[decltype(R)::value] = T(0); });
       add_S<i>(T(1), sS);                     // S              (:1231)
@@ -100,16 +106,16 @@ __global__ __launch_bounds__(64, 1) void fb_grad_fpass_kernel(const T* __restric
       } else {
         sfor<0, 6>([&](auto R) { e1[decltype(R)::value] = T(0); });
       }
-      mxS<i>(v[i], T(1), e2);                 // crm(v_i) S     (:1243)
+      mxS<i>(vi, T(1), e2);                   // crm(v_i) S     (:1243)
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; dv[i][r] += sel(own, ISQD ? sS[r] : sdq[r], T(0)); });
       add_mxS<i>(dv[i], qdv[i], da[i]);       // (:1170 / :1240)
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; da[i][r] += sel(own, ISQD ? e2[r] : e1[r], T(0)); });
       T Iv[6], Idv[6], d[6];
-      cmatvec<MatI, i>(v[i], Iv);
+      cmatvec<MatI, i>(vi, Iv);
       cmatvec<MatI, i>(dv[i], Idv);
       cmatvec<MatI, i>(da[i], d);
       fxv<true>(dv[i], Iv, d);                // (:1179-1185 / :1247-1252)
-      fxv<true>(v[i], Idv, d);
+      fxv<true>(vi, Idv, d);
       emit(I, d);
     });
   }
@@ -172,65 +178,90 @@ __global__ __launch_bounds__(64, 1) void fb_grad_bpass_kernel(const T* __restric
 template <class T>
 __global__ __launch_bounds__(64, 1) void fb_minv_bpass_kernel(const T* __restrict__ q, long long B, T* __restrict__ Minv,
                                                               T* __restrict__ F, T* __restrict__ U_out, T* __restrict__ D_out) {
-  const int sub = threadIdx.x % FB_MINV_L;
-  const long long b = (long long)blockIdx.x * (64 / FB_MINV_L) + threadIdx.x / FB_MINV_L;
-  if (b >= B) return;
+  // {U[6], 1/D} of every body, per configuration of the block: the column sweeps of the configuration's four lanes read
+  // them from here (same address: an LDS broadcast) instead of each lane holding 7 NB registers across the column loop
+  __shared__ T recs[64 / FB_MINV_L][N][8];
+  __shared__ T fbs[64 / FB_MINV_L][36];
+  const int sub = threadIdx.x % FB_MINV_L, slot = threadIdx.x / FB_MINV_L;
+  const long long b0 = (long long)blockIdx.x * (64 / FB_MINV_L) + slot;
+  const bool live = b0 < B;
+  const long long b = live ? b0 : B - 1;                // lanes beyond the batch repeat the last configuration and store nothing
   const T* qb = q + b * NV;
   T* Mb = Minv + b * (NV * NV);
   T* Fb = F + b * (6LL * NV * NV);                      // [mi][r][c] at (mi * 6 + r) * NV + c
   JTrig<T> tr[N];
   sfor<1, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qb[j + 5]); });
-  T U[N][6], Dinv[N];
-  T fb6[6][6];
   {
-    T IA[N][6][6];
-    sfor<0, N>([&](auto J) {
-      sfor<0, 6>([&](auto R) {
-        sfor<0, 6>([&](auto C) {
-          constexpr int j = decltype(J)::value, r = decltype(R)::value, c = decltype(C)::value;
-          IA[j][r][c] = T(IM[j][r * 6 + c]);
+    // articulated inertias, one subtree of the base after the other (only that subtree's IA is live)
+    T acc0[6][6];
+    sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; acc0[r][c] = T(IM[0][r * 6 + c]); }); });
+    sfor<1, N>([&](auto RT) {
+      constexpr int rt = decltype(RT)::value;
+      if constexpr (PARENT[rt] == 0) {
+        T IA[N][6][6];
+        sfor<1, N>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          if constexpr (fbp_child_root(j) == rt)
+            sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; IA[j][r][c] = T(IM[j][r * 6 + c]); }); });
         });
-      });
-    });
-    sfor_down<1, N>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int p = PARENT[i];
-      constexpr int si = fb_s_index(i);
-      sfor<0, 6>([&](auto R) { U[i][decltype(R)::value] = IA[i][decltype(R)::value][si]; });
-      const T D = U[i][si];
-      Dinv[i] = T(1) / D;
-      if (sub == 0) {
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U_out[(b * NV + i + 5) * 6 + r] = U[i][r]; });   // :697
-        D_out[b * NV + i + 5] = D;                                                                                     // :698 (holds D)
+        sfor_down<1, N>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          if constexpr (fbp_child_root(i) == rt) {
+            constexpr int p = PARENT[i];
+            constexpr int si = fb_s_index(i);
+            T U[6];
+            sfor<0, 6>([&](auto R) { U[decltype(R)::value] = IA[i][decltype(R)::value][si]; });
+            const T D = U[si];
+            const T Dinv = T(1) / D;
+            if (sub == 0) {
+              sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; recs[slot][i][r] = U[r]; });
+              recs[slot][i][6] = Dinv;
+              if (live) {
+                sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U_out[(b * NV + i + 5) * 6 + r] = U[r]; });   // :697
+                D_out[b * NV + i + 5] = D;                                                                                 // :698 (holds D)
+              }
+            }
+            T A[6][6];
+            sfor<0, 6>([&](auto C) {
+              constexpr int c = decltype(C)::value;
+              T col[6], y[6];
+              const T uc = U[c] * Dinv;
+              sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[r], uc, IA[i][r][c]); });
+              xform_T<i>(tr[i], col, y);
+              sfor<0, 6>([&](auto R) { A[decltype(R)::value][c] = y[decltype(R)::value]; });
+            });
+            sfor<0, 6>([&](auto R) {
+              constexpr int r = decltype(R)::value;
+              T y[6];
+              xform_T<i>(tr[i], A[r], y);
+              sfor<0, 6>([&](auto C) {
+                constexpr int c = decltype(C)::value;
+                if constexpr (p == 0) acc0[r][c] += y[c]; else IA[p][r][c] += y[c];
+              });
+            });
+          }
+        });
       }
-      T A[6][6];
-      sfor<0, 6>([&](auto C) {
-        constexpr int c = decltype(C)::value;
-        T col[6], y[6];
-        const T uc = U[i][c] * Dinv[i];
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[i][r], uc, IA[i][r][c]); });
-        xform_T<i>(tr[i], col, y);
-        sfor<0, 6>([&](auto R) { A[decltype(R)::value][c] = y[decltype(R)::value]; });
-      });
-      sfor<0, 6>([&](auto R) {
-        constexpr int r = decltype(R)::value;
-        T y[6];
-        xform_T<i>(tr[i], A[r], y);
-        sfor<0, 6>([&](auto C) { IA[p][r][decltype(C)::value] += y[decltype(C)::value]; });
-      });
     });
+    T fb6[6][6];
+    fb_inv6(acc0, fb6);
     if (sub == 0) {
-      // U[0:6] = IA_0 S = IA_0 (:680); Dinv[0:6] stays 0 (the reference never writes it)
-      sfor<0, 6>([&](auto R) {
-        sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; U_out[(b * NV + r) * 6 + c] = IA[0][r][c]; });
-        D_out[b * NV + decltype(R)::value] = T(0);
-      });
+      sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; fbs[slot][r * 6 + c] = fb6[r][c]; }); });
+      if (live) {
+        // U[0:6] = IA_0 S = IA_0 (:680); Dinv[0:6] stays 0 (the reference never writes it); the base block of Minv (:685)
+        sfor<0, 6>([&](auto R) {
+          sfor<0, 6>([&](auto C) {
+            constexpr int r = decltype(R)::value, c = decltype(C)::value;
+            U_out[(b * NV + r) * 6 + c] = acc0[r][c];
+            Mb[r * NV + c] = fb6[r][c];
+          });
+          D_out[b * NV + decltype(R)::value] = T(0);
+        });
+      }
     }
-    fb_inv6(IA[0], fb6);
   }
-  if (sub == 0) {
-    sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; Mb[r * NV + c] = fb6[r][c]; }); });   // :685
-  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 #pragma clang loop unroll(disable)
   for (int jb = 1 + sub; jb < N; jb += FB_MINV_L) {
     const int j = jb + 5;
@@ -239,23 +270,31 @@ __global__ __launch_bounds__(64, 1) void fb_minv_bpass_kernel(const T* __restric
       constexpr int i = decltype(I)::value;
       constexpr unsigned long long mask = fb_subtree_mask(i);
       const bool insub = ((mask >> jb) & 1ull) != 0;
-      T m = sel(jb == i, Dinv[i], -(Dinv[i] * S_dot<i>(Fj)));           // :700, :702-708
+      T U[6];
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[r] = recs[slot][i][r]; });
+      const T Dinv = recs[slot][i][6];
+      T m = sel(jb == i, Dinv, -(Dinv * S_dot<i>(Fj)));                // :700, :702-708
       T t[6], y[6];
-      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(U[i][r], m, Fj[r]); });   // :721-723
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(U[r], m, Fj[r]); });   // :721-723
       xform_T<i>(tr[i], t, y);                                                                              // :724-726
       if (insub) {
-        Mb[(i + 5) * NV + j] = m;
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fb[((i + 5) * 6 + r) * NV + j] = t[r]; Fj[r] = y[r]; });
+        if (live) {
+          Mb[(i + 5) * NV + j] = m;
+          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fb[((i + 5) * 6 + r) * NV + j] = t[r]; });
+        }
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fj[r] = y[r]; });
       }
     });
-    // what reached the base sits in the base's F slot, matrix index 5 (:724 with parent_ind + 5); its rows :686-691
-    sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fb[(5 * 6 + r) * NV + j] = Fj[r]; });
-    sfor<0, 6>([&](auto R) {
-      constexpr int r = decltype(R)::value;
-      T o = T(0);
-      sfor<0, 6>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(-fb6[r][k], Fj[k], o); });
-      Mb[r * NV + j] = o;
-    });
+    if (live) {
+      // what reached the base sits in the base's F slot, matrix index 5 (:724 with parent_ind + 5); its rows :686-691
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fb[(5 * 6 + r) * NV + j] = Fj[r]; });
+      sfor<0, 6>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        T o = T(0);
+        sfor<0, 6>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(-fbs[slot][r * 6 + k], Fj[k], o); });
+        Mb[r * NV + j] = o;
+      });
+    }
   }
 }
 

@@ -335,25 +335,53 @@ __global__ __launch_bounds__(64) void rnea_bpass_kernel(const T* __restrict__ q,
   JTrig<T> tr[N];
   T qv[N];
   sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; qv[j] = q[b * N + j]; });
-  T f[N][6];
-  sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; f[j][r] = f_io[b * K6 + r * N + j]; }); });
   sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(qv[j]); });
   T c[N];
-  sfor_down<0, N>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    constexpr int p = PARENT[j];
-    c[j] = S_dot<j>(f[j]);
-    if constexpr (p >= 0) {
-      T t[6];
-      xform_T<j>(tr[j], f[j], t);
-      sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+  if constexpr (6 * N * sizeof(T) > 6 * 16 * sizeof(double)) {
+    // Big robots (30 bodies in fp64: 6 n doubles = 360 registers, scratch): f never lives in registers as a whole.  The
+    // block's [64][6 n] tensor comes in through the LDS image (coalesced), every lane accumulates child -> parent on its
+    // own image row (stride odd: conflict-free), and the image leaves as it is.
+    constexpr int KP = odd_pad<K6>();
+    for (int g = lane; g < nvalid * K6; g += 64) {
+      const int cfg = g / K6;
+      lds[cfg * KP + (g - cfg * K6)] = f_io[cfg0 * K6 + g];
     }
-  });
-  __syncthreads();   // every lane has read its f before the tile is written back
-  T tmp[K6];
-  sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
-  staged_store<K6>(lds, tmp, f_io + cfg0 * K6, lane, nvalid);
-  staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
+    __syncthreads();
+    T* mine = lds + lane * KP;
+    sfor_down<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      T fj[6];
+      sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; fj[r] = mine[r * N + j]; });
+      c[j] = S_dot<j>(fj);
+      if constexpr (p >= 0) {
+        T t[6];
+        xform_T<j>(tr[j], fj, t);
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; mine[r * N + p] += t[r]; });
+      }
+    });
+    __syncthreads();
+    flush_tile<K6>(lds, f_io + cfg0 * K6, lane, nvalid);
+    staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
+  } else {
+    T f[N][6];
+    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { constexpr int j = decltype(J)::value, r = decltype(R)::value; f[j][r] = f_io[b * K6 + r * N + j]; }); });
+    sfor_down<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      constexpr int p = PARENT[j];
+      c[j] = S_dot<j>(f[j]);
+      if constexpr (p >= 0) {
+        T t[6];
+        xform_T<j>(tr[j], f[j], t);
+        sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += t[decltype(R)::value]; });
+      }
+    });
+    __syncthreads();   // every lane has read its f before the tile is written back
+    T tmp[K6];
+    sfor<0, N>([&](auto J) { sfor<0, 6>([&](auto R) { tmp[decltype(R)::value * N + decltype(J)::value] = f[decltype(J)::value][decltype(R)::value]; }); });
+    staged_store<K6>(lds, tmp, f_io + cfg0 * K6, lane, nvalid);
+    staged_store<N>(lds, c, c_out + cfg0 * N, lane, nvalid);
+  }
 }
 
 #endif  // RBD_NEED_RNEA
@@ -2230,7 +2258,7 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
   // fp32 robots whose default is the tree kernel never build the column kernel (Atlas: 404 VGPRs of
   // code nobody runs); fp64 x big tree would need > 512 VGPRs and is not built either.
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
-  constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
+  constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || (N <= 12 && rbdm::MAXDEPTH <= 5));   // fp64: the root path's S / psid / psidd (36 registers per body) must fit 512 VGPRs without scratch
   if constexpr (TREE_BUILT) {
     constexpr size_t lds = tree_lds_bytes<T>();
     static_assert(!TREE_ONLY || lds <= 160 * 1024, "tree kernel is the only gradient kernel of this robot but does not fit LDS");
@@ -2301,7 +2329,7 @@ int grad_kernel_name(int64_t B, char* buf, size_t len) {
   const char* t = sizeof(T) == 4 ? "float" : "double";
   if (grad_use_cols<T>(B)) { std::snprintf(buf, len, "rnea_grad_cols_kernel<%s,true>", t); return 0; }
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
-  constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || N <= 12);
+  constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || (N <= 12 && rbdm::MAXDEPTH <= 5));   // fp64: the root path's S / psid / psidd (36 registers per body) must fit 512 VGPRs without scratch
   bool tree = TREE_ONLY;
   if constexpr (TREE_BUILT) tree = tree || (rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE && tree_lds_bytes<T>() <= 160 * 1024);
   if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);

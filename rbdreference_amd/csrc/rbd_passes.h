@@ -246,9 +246,16 @@ __global__ __launch_bounds__(64) void minv_fpass_kernel(const T* __restrict__ q,
                                                         T* __restrict__ F, const T* __restrict__ U_in,
                                                         const T* __restrict__ D_in) {
   const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+  // big robots in fp64 (30 bodies: the column's F of every body is 360 registers): sin / cos wait in lane-private LDS
+  constexpr bool TRIG_LDS = N * sizeof(T) > 128;
+  __shared__ T trig_lds[TRIG_LDS ? 2 * N : 1][TRIG_LDS ? 64 : 1];
+  if (b >= B) return;                                        // (no barrier below)
   JTrig<T> tr[N];
-  sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tr[j] = make_trig<j>(q[b * N + j]); });
+  sfor<0, N>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    tr[j] = make_trig<j>(q[b * N + j]);
+    if constexpr (TRIG_LDS) { trig_lds[2 * j][threadIdx.x] = tr[j].s; trig_lds[2 * j + 1][threadIdx.x] = tr[j].c; }
+  });
   T* Mb = Minv + b * (N * N);
   T* Fb = F + b * (N * 6 * N);
   const T* Ub = U_in + b * (N * 6);
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(64) void minv_fpass_kernel(const T* __restrict__ q,
       } else {
         T Ui[6];
         sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Ui[r] = Ub[i * 6 + r]; });
+        if constexpr (TRIG_LDS) { tr[i].s = trig_lds[2 * i][threadIdx.x]; tr[i].c = trig_lds[2 * i + 1][threadIdx.x]; }
         xform<i>(tr[i], Ff[p], Ff[i]);
         m = fma_(-(T(1) / Db[i]), dot6(Ui, Ff[i]), m);           // Minv[i, c] -= (1/D)(U^T X) F[p][:, c]  (:771-773)
         Mb[i * N + c] = m;

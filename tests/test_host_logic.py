@@ -152,29 +152,36 @@ def test_product_package_never_imports_the_oracle():
 
 
 @pytest.mark.skipif(not HAVE_HIPCC, reason="needs the ROCm LLVM tools")
-def test_fp32_kernels_of_built_libraries_do_not_spill():
-    """DESIGN.md §5 claims every fp32 kernel of every test robot is spill-free (spills are HBM
-    traffic, §3).  Checked on whatever per-robot libraries are present (build() makes all seven);
-    reads the code-object metadata only, no GPU."""
+def test_kernels_of_built_libraries_do_not_spill():
+    """every kernel of every test robot, fp32 AND fp64 (the reference's own arithmetic), is free of
+    scratch memory (spills are HBM traffic, §3) -- with ONE exception on record: the two-lane column gradient kernel
+    of the 30-body robot in fp64 (its 18 x 60 accumulators and both lanes' sweeps need more than 512 VGPRs; fp32
+    serves that robot with the tree kernel).  Checked on whatever per-robot libraries are present (build() makes
+    all of them); reads the code-object metadata only, no GPU."""
     import glob
     import subprocess
     import sys
     libs = sorted(glob.glob(os.path.join(ROOT, "rbdreference_amd", "_build", "librbd_*_*.so")))
-    libs = [l for l in libs if l.count(".") == 1]            # skip tagged experiment builds
+    libs = [l for l in libs if l.count(".") == 1]            # skip tagged experiment builds and family libraries
     if not libs:
         pytest.skip("no per-robot library built yet")
-    bad = []
+    known = {("atlas_like", "rnea_grad_kernel<double, true, false>"), ("atlas_like", "rnea_grad_kernel<double, false, false>")}
+    bad, seen_known = [], set()
     for lib in libs:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), lib],
                              capture_output=True, text=True, check=True).stdout
+        robot = os.path.basename(lib)[len("librbd_"):].rsplit("_", 1)[0]
         for line in out.splitlines():
             name = line.split("vgpr=")[0].strip()
             spill = int(line.rsplit("spill=", 1)[1])
             scratch = int(line.split("scratch=")[1].split()[0])
             # `spill` with scratch == 0 are copies into the accumulator half of a lone wave's 512-entry
             # register file (v_accvgpr_write / read): registers, not memory traffic
-            if "<float" in name and scratch:
-                bad.append((os.path.basename(lib), name, spill, scratch))
+            if scratch:
+                if (robot, name) in known:
+                    seen_known.add((robot, name))
+                else:
+                    bad.append((os.path.basename(lib), name, spill, scratch))
     assert not bad, bad
 
 
