@@ -988,7 +988,21 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   // groups: the block handles group blockIdx.x % split of configurations blockIdx.x / split (the
   // group is the FAST index, so that the blocks that write neighbouring rows of a configuration run
   // close in time and L2 can merge their partial cache lines)
-  const long long cfg0 = (long long)(blockIdx.x / split) * CFGS;
+  // XCD-aware: blocks x and x + 8 share an XCD (observed dispatch order; speed only, never correctness), and each XCD has
+  // its own L2.  The `split` blocks of one batch of configurations read the same input rows and write neighbouring
+  // rows of the same matrices, so they are given indices 8 apart: the inputs are fetched into ONE L2 instead of
+  // `split` (quadruped fp64 B = 65 536: FETCH_SIZE x 2 was 75.8 MB for 18.9 MB of inputs) and partial lines of
+  // neighbouring rows meet in the same L2.  Index within the XCD = (configuration block, group), group fastest.
+#ifdef RBD_EXP_NO_XCD_MAP
+  const long long cblk = blockIdx.x / split;
+  const int gsel_x = (int)(blockIdx.x % split);
+#else
+  const long long kx = blockIdx.x >> 3;
+  const long long cblk = split > 1 ? (kx / split) * 8 + (blockIdx.x & 7) : blockIdx.x;
+  const int gsel_x = split > 1 ? (int)(kx % split) : 0;
+  if (cblk * CFGS >= B) return;          // (the grid is rounded up to a multiple of 8 configuration blocks; no barrier has been passed)
+#endif
+  const long long cfg0 = cblk * CFGS;
   const long long rem = B - cfg0;
   const int nvalid = rem < CFGS ? (int)rem : CFGS;
   const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
@@ -1021,7 +1035,7 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   };
   // split > 1: one block per (configurations, group) -- the groups are independent problems, so
   // giving each its own blocks multiplies the wave count and divides a wave's serial length
-  const int gsel = split > 1 ? (int)(blockIdx.x % split) : -1;
+  const int gsel = split > 1 ? gsel_x : -1;
   sfor<0, N>([&](auto Rt) {
    constexpr int rt = decltype(Rt)::value;
    if constexpr (grp_head(rt)) {
@@ -2168,8 +2182,13 @@ int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_
   // independent root subtrees get their own blocks (not with the fused -Minv epilogue, whose Minv
   // tile is shared by the groups)
   const int split = (!FDG && GRAD_PER_ROOT && n_groups() > 1) ? n_groups() : 1;
-  if (blocks * split > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
-  hipLaunchKernelGGL(k, dim3((unsigned)(blocks * split)), dim3(2 * CFGS), lds, (hipStream_t)stream, q, qd, qdd, gravity,
+#ifdef RBD_EXP_NO_XCD_MAP
+  const int64_t grid = blocks * split;
+#else
+  const int64_t grid = split > 1 ? ((blocks + 7) / 8 * 8) * split : blocks;     // whole XCD rounds (the kernel's block -> (configurations, group) map)
+#endif
+  if (grid > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(2 * CFGS), lds, (hipStream_t)stream, q, qd, qdd, gravity,
                      use_damping, (long long)B, c, dc_du, minv_in, split);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
