@@ -251,6 +251,10 @@ def main():
 
     step = make_step(args.scaling)
     rows_rank = step.B
+    # strong scaling = shards of ONE global batch: kernel selection is pinned to the global row count, as
+    # rbdreference_amd.dist.ShardedRBD does, so that every rank runs the kernel the unsharded call would run
+    from rbdreference_amd._lib import RBD_OPT_SELECT_BATCH
+    rbd._lib.set_option(RBD_OPT_SELECT_BATCH, B if (args.scaling == "strong" and world > 1) else 0)
 
     # Clock ramp (untimed, before the W warm-up steps): from idle the GPU needs ~25 ms of sustained
     # load to reach its working clock -- with only 10 warm-up launches (3 ms) the timed launches
@@ -269,12 +273,15 @@ def main():
     if world > 1:                            # the other scaling mode, same run, reported beside the headline
         omode = "weak" if args.scaling == "strong" else "strong"
         ostep = make_step(omode)
+        rbd._lib.set_option(RBD_OPT_SELECT_BATCH, B if omode == "strong" else 0)
         ow, ok = timed_steps(ostep, args.steps, args.warmup, dist, dev)
+        rbd._lib.set_option(RBD_OPT_SELECT_BATCH, 0)
         orows = B if omode == "strong" else world * B
         other = {"scaling": omode, "value": orows * args.steps / ow, "unit": "evals/s", "ms_per_step": ow / args.steps * 1e3,
                  "kernel_ms": ok, "rows_per_gpu": ostep.B, "global_batch": orows}
         del ostep
 
+    rbd._lib.set_option(RBD_OPT_SELECT_BATCH, 0)
     # parity spot-check of what was just timed (first 256 rows of buffer set 0 vs the fp64 oracle), rank 0
     parity = None
     if rank == 0:
