@@ -1,0 +1,99 @@
+/* rbd_generic.h -- C-ABI of the MODEL-HANDLE library (librbd_generic.so): the same batched rnea / rnea_grad /
+ * minv / forward_dynamics(_grad) as include/rbd_hip.h, for ANY robot, with the model passed at run time.
+ *
+ * Why it exists.  The per-robot libraries of rbd_hip.h are compiled against the robot (tens of seconds for an arm,
+ * minutes for a humanoid, and they need hipcc on the machine).  This library is compiled ONCE, needs no compiler on
+ * the user's machine, and serves a new robot the moment rbd_model_create() returns: rbdreference_amd/api.py routes
+ * calls here until the specialised library of the robot is ready, and stays here if it never will be.  It is the
+ * interface SURVEY.md §8b sketches (`rbd_model_create(desc)` + entry points taking the handle).
+ *
+ * What it computes.  The reference's own recursions, literally, on dense 6x6 operands in body coordinates:
+ *   rbd_g_rnea       /root/reference/RBDReference.py:559-628   (rnea_fpass, rnea_bpass, rnea)
+ *   rbd_g_rnea_grad  :1127-1368  (rnea_grad_fpass_dq/dqd, rnea_grad_bpass_dq/dqd incl. the literal fxS term, rnea_grad)
+ *   rbd_g_minv       :630-806    (minv_bpass, minv_fpass, minv; fixed-base branches)
+ *   rbd_g_forward_dynamics(_grad)  :1371-1384
+ * Joints: X_i(q) = X0_i + Xs_i f1(q) + Xc_i f2(q) with (f1, f2) = (sin q, cos q) for joint_type 0 (revolute, any
+ * axis) and (q, 0) for joint_type 1 (prismatic) -- SURVEY.md Appendix A: three samples of the robot's Xmat closure
+ * recover the three matrices exactly; S_i is any 6-vector.  Fixed base, 1-DoF joints, n <= RBD_G_MAX_BODIES.
+ * One configuration per lane, per-lane state in private memory: correct and general, several times slower than the
+ * specialised kernels (DESIGN.md §3.8 has the measured ratio) -- a first-use path, not the headline path.
+ *
+ * Conventions: as rbd_hip.h (device pointers, dense row-major, batch outermost, caller owns every buffer, `stream`
+ * is a hipStream_t as void*, 0 = OK, <0 = RBD_G_ERR_*, >0 = hipError_t; rbd_g_last_error() is thread-local; no C++
+ * exception crosses the boundary).  The handle is immutable after creation: concurrent calls are safe.  Calls run on
+ * the device the model was created on (the calling thread's current device must be that device).
+ */
+#ifndef RBD_GENERIC_H
+#define RBD_GENERIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBD_G_MAX_BODIES 64
+#define RBD_G_ABI_VERSION 1
+
+#define RBD_G_ERR_ARG (-1)
+#define RBD_G_ERR_UNSUPPORTED (-2)
+#define RBD_G_ERR_WORKSPACE (-3)
+
+typedef struct rbd_model rbd_model;
+
+/* Host arrays, float64, read once by rbd_model_create (nothing is retained). */
+typedef struct rbd_model_desc {
+  int32_t abi_version;        /* RBD_G_ABI_VERSION                                                        */
+  int32_t n;                  /* bodies == joints == velocities                                           */
+  const int32_t* parent;      /* [n]   -1 = child of the fixed base; parent[i] < i (RBDReference.py:569)   */
+  const int32_t* joint_type;  /* [n]   0: X = X0 + Xs sin q + Xc cos q;  1: X = X0 + Xs q                  */
+  const double* S;            /* [n,6] motion subspace (get_S_by_id)                                      */
+  const double* X0;           /* [n,36] row-major 6x6                                                     */
+  const double* Xs;           /* [n,36]                                                                   */
+  const double* Xc;           /* [n,36] (ignored for joint_type 1)                                        */
+  const double* I;            /* [n,36] spatial inertia (get_Imat_by_id)                                  */
+  const double* damping;      /* [n]   (get_damping_by_id)                                                */
+} rbd_model_desc;
+
+int rbd_g_abi_version(void);
+const char* rbd_g_last_error(void);
+
+/* Validates the description, uploads an fp32 and an fp64 copy to `device`, returns the handle in *out. */
+int rbd_model_create(const rbd_model_desc* desc, int device, rbd_model** out);
+void rbd_model_destroy(rbd_model* m);
+int rbd_model_n(const rbd_model* m);
+
+/* Replaces RBDReference.rnea (RBDReference.py:623): c [B,n]; v, a, f [B,6,n] (nullable, f accumulated);
+ * qdd NULL = the reference's qdd=None. */
+int rbd_g_rnea_f32(const rbd_model*, const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
+                   float* c, float* v, float* a, float* f, void* stream);
+int rbd_g_rnea_f64(const rbd_model*, const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
+                   double* c, double* v, double* a, double* f, void* stream);
+
+/* Replaces RBDReference.rnea_grad (:1345): dc_du [B,n,2n] = [dc_dq | dc_dqd]; c [B,n] nullable. */
+int rbd_g_rnea_grad_f32(const rbd_model*, const float* q, const float* qd, const float* qdd, float gravity,
+                        int use_damping, int64_t B, float* c, float* dc_du, void* stream);
+int rbd_g_rnea_grad_f64(const rbd_model*, const double* q, const double* qd, const double* qdd, double gravity,
+                        int use_damping, int64_t B, double* c, double* dc_du, void* stream);
+
+/* Replaces RBDReference.minv (:785): Minv [B,n,n]; output_dense = 0 leaves a zero strict lower triangle. */
+int rbd_g_minv_f32(const rbd_model*, const float* q, int64_t B, int output_dense, float* Minv, void* stream);
+int rbd_g_minv_f64(const rbd_model*, const double* q, int64_t B, int output_dense, double* Minv, void* stream);
+
+/* Replaces RBDReference.forward_dynamics / forward_dynamics_grad (:1371-1384): qdd [B,n] = Minv (u - c);
+ * dqdd_du [B,n,2n] = -Minv [dc_dq | dc_dqd] at that qdd.  `workspace`: rbd_g_fd_workspace_bytes(m, B, elem, grad). */
+size_t rbd_g_fd_workspace_bytes(const rbd_model*, int64_t B, int elem_size, int with_grad);
+int rbd_g_forward_dynamics_f32(const rbd_model*, const float* q, const float* qd, const float* u, float gravity, int64_t B,
+                               float* qdd, void* workspace, size_t workspace_bytes, void* stream);
+int rbd_g_forward_dynamics_f64(const rbd_model*, const double* q, const double* qd, const double* u, double gravity, int64_t B,
+                               double* qdd, void* workspace, size_t workspace_bytes, void* stream);
+int rbd_g_forward_dynamics_grad_f32(const rbd_model*, const float* q, const float* qd, const float* u, float gravity, int64_t B,
+                                    float* qdd, float* dqdd_du, void* workspace, size_t workspace_bytes, void* stream);
+int rbd_g_forward_dynamics_grad_f64(const rbd_model*, const double* q, const double* qd, const double* u, double gravity, int64_t B,
+                                    double* qdd, double* dqdd_du, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBD_GENERIC_H */

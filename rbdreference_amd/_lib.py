@@ -124,9 +124,18 @@ class RbdLibrary:
     whole library's 40 s; minutes for a 30-body robot); as soon as the full library is ready every call goes to it.
     ``RBD_LAZY_BUILD=0`` (or ``lazy=False``) restores the blocking build.  ``.lib`` is always the FULL library (it
     waits for the background build if there is one).  Options are process-wide per library file, so they are
-    remembered here and applied to every library of the robot as it is loaded."""
+    remembered here and applied to every library of the robot as it is loaded.
 
-    def __init__(self, model: PackedModel, build: bool = True, lazy=None):
+    ``generic`` ('auto' | 'only' | 'never'; default from ``RBD_GENERIC``, else 'auto'): the MODEL-HANDLE library
+    (include/rbd_generic.h, ``generic.GenericModel``) serves rnea / rnea_grad / minv / forward_dynamics(_grad) of a
+    fixed-base robot with no per-robot compilation at all.  'auto': it answers while the robot's own library is being
+    built in the background (first call after ``RBDReference(robot)`` returns in milliseconds instead of after a
+    family build) and keeps answering if that build cannot happen (no hipcc on the machine); the other entry points
+    still wait for their family library.  'only': nothing is built or loaded per robot.  'never': as before.
+    The generic and the specialised kernels agree to rounding, not bit for bit; ``ShardedRBD`` therefore waits for the
+    full library before it computes (dist.py)."""
+
+    def __init__(self, model: PackedModel, build: bool = True, lazy=None, generic=None):
         import threading
         from .build import full_library_ready
         self.model = model
@@ -140,6 +149,16 @@ class RbdLibrary:
         self._tls = threading.local()
         if lazy is None:
             lazy = os.environ.get("RBD_LAZY_BUILD", "1") != "0"
+        if generic is None:
+            generic = {"0": "never", "1": "auto", "": "auto"}.get(os.environ.get("RBD_GENERIC", "auto"), os.environ.get("RBD_GENERIC", "auto"))
+        if generic not in ("auto", "only", "never"):
+            raise ValueError("generic must be 'auto', 'only' or 'never'")
+        self._generic_mode = "never" if model.floating else generic
+        self._generic = None
+        if self._generic_mode == "only":
+            from .generic import GenericModel
+            self._generic = GenericModel(model, build=build)       # raises if the library is missing and cannot be built
+            return
         if build and lazy and not model.floating and not full_library_ready(model):
             def work():
                 try:
@@ -180,13 +199,58 @@ class RbdLibrary:
     def _full_if_ready(self):
         if self._full is not None:
             return self._full
+        if self._generic_mode == "only":
+            return None
         if self._bg is not None and not self._bg.is_alive():
+            if self._bg_err is not None and self._generic_serving() is not None:
+                return None                     # no per-robot library on this machine: the generic one keeps serving
             return self.lib
         return None
+
+    def _generic_serving(self):
+        """The GenericModel of this robot, or None (mode 'never', floating base, or its library cannot be had)."""
+        if self._generic_mode == "never":
+            return None
+        if self._generic is None:
+            with self._lock:
+                if self._generic is None:
+                    try:
+                        from .generic import GenericModel
+                        self._generic = GenericModel(self.model, build=True)
+                    except Exception:           # noqa: BLE001  (no library and no compiler: the family path decides)
+                        self._generic_mode = "never"
+                        return None
+        return self._generic
+
+    def wait_specialized(self):
+        """Block until the robot's own full library is loaded (no-op in mode 'only'); returns self."""
+        if self._generic_mode != "only":
+            self.lib
+        return self
+
+    def serving(self, base: str, sfx: str, has_qdd: bool = True):
+        """The library object (full, family or generic) that answers entry point `base` right now."""
+        from .build import family_of
+        lib = self._full_if_ready()
+        if lib is not None:
+            return lib
+        fam = (family_of(base, has_qdd), sfx or "f32")
+        if fam in self._fams:
+            return self._fams[fam]
+        g = self._generic_serving()
+        if g is not None and g.serves(base):
+            return g
+        if self._generic_mode == "only":
+            raise RbdError(RBD_ERR_UNSUPPORTED, f"{base}: not served by the model-handle library (generic='only')")
+        if self._bg_err is not None:
+            raise self._bg_err
+        return self._family(*fam)
 
     @property
     def lib(self):
         """The FULL library (blocks until a background build has finished)."""
+        if self._generic_mode == "only":
+            raise RuntimeError("generic='only': no per-robot library is loaded")
         with self._lock:
             if self._full is None:
                 if self._bg is not None:
@@ -215,16 +279,17 @@ class RbdLibrary:
     def fn(self, base: str, sfx: str, has_qdd: bool = True):
         """C entry point ``<base>_<sfx>`` (sfx 'f32' | 'f64'; '' for the suffix-less ones): from the full library when
         it is ready, else from the family library that serves it (built now if need be)."""
-        from .build import family_of
-        lib = self._full_if_ready()
-        if lib is None:
-            lib = self._family(family_of(base, has_qdd), sfx or "f32")
+        lib = self.serving(base, sfx, has_qdd)
         self._tls.lib = lib
         return getattr(lib, f"{base}_{sfx}" if sfx else base)
 
+    def served_by_generic(self) -> bool:
+        """True if the calling thread's last ``fn()`` / ``serving()`` answer was the model-handle library."""
+        return bool(getattr(getattr(self._tls, "lib", None), "is_generic", False))
+
     def check(self, rc: int):
         if rc != 0:
-            lib = getattr(self._tls, "lib", None) or self._full_if_ready() or next(iter(self._fams.values()), None) or self.lib
+            lib = getattr(self._tls, "lib", None) or self._full_if_ready() or next(iter(self._fams.values()), None) or self._generic or self.lib
             raise RbdError(rc, (lib.rbd_last_error() or b"").decode())
 
     def _loaded(self):
@@ -232,22 +297,27 @@ class RbdLibrary:
 
     def set_option(self, option: int, value: int) -> None:
         with self._lock:
-            libs = self._loaded() or [self.lib]
-            for lib in libs:
+            libs = self._loaded()
+            if not libs and self._generic_serving() is None:
+                libs = [self.lib]
+            for lib in libs:                     # (the model-handle library has one kernel per entry point: nothing to select)
                 self._tls.lib = lib
                 self.check(lib.rbd_set_option(option, value))
             self._opts[option] = value
 
     def get_option(self, option: int) -> int:
         with self._lock:
-            libs = self._loaded() or [self.lib]
-            return int(libs[0].rbd_get_option(option))
+            libs = self._loaded()
+            if not libs and self._generic_serving() is not None:
+                return int(self._opts.get(option, 0))
+            return int((libs or [self.lib])[0].rbd_get_option(option))
 
     def kernel_name(self, op: int, elem_size: int, B: int) -> str:
         """Name of the (dominant) kernel entry point `op` launches for B rows (host-side, no GPU)."""
-        lib = self._full_if_ready()
-        if lib is None:
-            lib = self._family({RBD_OP_RNEA: "rnea", RBD_OP_RNEA_GRAD: "grad", RBD_OP_MINV: "minv"}[op], "f32" if elem_size == 4 else "f64")
+        base = {RBD_OP_RNEA: "rbd_rnea", RBD_OP_RNEA_GRAD: "rbd_rnea_grad", RBD_OP_MINV: "rbd_minv"}[op]
+        lib = self.serving(base, "f32" if elem_size == 4 else "f64")
+        if getattr(lib, "is_generic", False):
+            return lib.kernel_name(op, elem_size)
         self._tls.lib = lib
         buf = ctypes.create_string_buffer(128)
         self.check(lib.rbd_kernel_name(op, elem_size, B, buf, len(buf)))

@@ -23,10 +23,13 @@ __all__ = ["RBDReference"]
 
 
 class RBDReference:
-    def __init__(self, robotObj, build: bool = True):
+    def __init__(self, robotObj, build: bool = True, generic=None):
+        """``generic`` ('auto' | 'only' | 'never', default ``RBD_GENERIC`` or 'auto'): whether the model-handle library
+        (include/rbd_generic.h) may answer rnea / rnea_grad / minv / forward_dynamics(_grad) while -- or instead of --
+        the robot's own compiled library (``_lib.RbdLibrary``)."""
         self.robot = robotObj                     # RBDReference.py:7
         self.model: PackedModel = pack_robot(robotObj)
-        self._lib = RbdLibrary(self.model, build=build)
+        self._lib = RbdLibrary(self.model, build=build, generic=generic)
         self.n = self.model.n            # bodies
         self.nv = self.model.nv          # columns of q, qd, qdd, c: n, or n + 5 with a floating base
 
@@ -91,11 +94,11 @@ class RBDReference:
 
     def _minv_ws(self, B: int, esz: int) -> int:
         """rbd_minv_workspace_bytes from the library that will serve the rbd_minv call of that precision."""
-        lib = self._lib._full_if_ready() or self._lib._family("minv", "f32" if esz == 4 else "f64")
+        lib = self._lib.serving("rbd_minv", "f32" if esz == 4 else "f64")
         return int(lib.rbd_minv_workspace_bytes(B, esz))
 
     def _fd_ws(self, B: int, esz: int) -> int:
-        lib = self._lib._full_if_ready() or self._lib._family("fd", "f32" if esz == 4 else "f64")
+        lib = self._lib.serving("rbd_forward_dynamics", "f32" if esz == 4 else "f64")
         return int(lib.rbd_fd_workspace_bytes(B, esz))
 
     @staticmethod
@@ -443,7 +446,8 @@ class RBDReference:
         with torch.cuda.device(dev):
             qdd = torch.empty((B, self.nv), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
-            if not want_grad and self.model.floating:   # rnea (bias force) + minv + one product: scratch for c and Minv
+            generic = getattr(self._lib.serving("rbd_forward_dynamics", "f32" if esz == 4 else "f64"), "is_generic", False)
+            if not want_grad and (self.model.floating or generic):   # rnea (bias force) + minv + one product: scratch for c and Minv
                 wsb = int(self._fd_ws(B, esz))
                 ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
                 self._lib.check(self._fn("rbd_forward_dynamics", dt)(

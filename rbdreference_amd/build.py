@@ -326,6 +326,51 @@ def full_library_ready(m: PackedModel) -> bool:
     return _up_to_date(lib_path(m), _sources_digest(m, list(HIPCC_FLAGS)))
 
 
+# ---- the model-handle library (include/rbd_generic.h): one build for every robot ------------------------------------
+GENERIC_SRC = os.path.join(HERE, "csrc_generic", "rbd_generic.hip")
+GENERIC_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def generic_lib_path() -> str:
+    return os.path.join(BUILD_DIR, "librbd_generic.so")
+
+
+def _generic_digest() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in (GENERIC_SRC, os.path.join(os.path.dirname(HERE), "include", "rbd_generic.h")):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(GENERIC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def generic_library_ready() -> bool:
+    return _up_to_date(generic_lib_path(), _generic_digest())
+
+
+def build_generic(force: bool = False) -> str:
+    """Compile librbd_generic.so (robot-independent: the model is a run-time table).  ~15 s, once per source change;
+    `__graft_entry__.build()` / an install step does it, so a user's machine needs no compiler for it."""
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    out = generic_lib_path()
+    digest = _generic_digest()
+    if not force and _up_to_date(out, digest):
+        return out
+    with _BuildLock(out):
+        if not force and _up_to_date(out, digest):
+            return out
+        uniq = f"{os.getpid()}.{threading.get_ident()}"
+        tmp = f"{out}.{uniq}.tmp"
+        _run([hipcc_path(), *GENERIC_FLAGS, GENERIC_SRC, "-o", tmp], "generic library", 1e9)
+        os.replace(tmp, out)
+        stamp_tmp = f"{out}.stamp.{uniq}.tmp"
+        with open(stamp_tmp, "w") as f:
+            f.write(digest + "\n")
+        os.replace(stamp_tmp, out + ".stamp")
+    return out
+
+
 def build_models_parallel(models, force: bool = False, jobs: Optional[int] = None) -> list:
     """Build several per-robot libraries concurrently (one hipcc process each)."""
     from concurrent.futures import ThreadPoolExecutor

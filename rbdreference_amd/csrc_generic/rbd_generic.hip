@@ -1,0 +1,697 @@
+// rbd_generic.hip -- librbd_generic.so: the MODEL-HANDLE library of include/rbd_generic.h.
+//
+// One configuration per lane; the robot is a run-time table in device memory (wave-uniform indices -> scalar loads);
+// per-lane state lives in arrays indexed by body, i.e. in private memory.  The arithmetic is the reference's own
+// recursion in body coordinates on dense 6x6 operands (/root/reference/RBDReference.py:559-628, :630-806, :1127-1368,
+// :1371-1384), reorganised per derivative COLUMN so that a lane never holds the (6, n, NB) tensors:
+//   - rnea_grad: column c of dv / da / df lives only on the bodies of subtree(c) (forward recursions :1157-1185,
+//     :1229-1252) and, in the backward sweep, on the ancestors of c (:1284-1294, :1325-1341);
+//   - minv: column c of F climbs the root path of c in the backward sweep (:702-726) and is rebuilt body by body in
+//     the forward sweep (:771-781); only rows <= c of the column are kept (the upper triangle, mirrored for
+//     output_dense, :799-804).
+// This is the first-use path (no compiler, no wait); the specialised per-robot kernels (rbd_kernels.hip) are the fast path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/rbd_generic.h"
+
+#define GDEV __device__ __forceinline__
+
+namespace rbdg {
+
+constexpr int MB = RBD_G_MAX_BODIES;
+
+template <class T>
+struct DevModel {
+  int n;
+  int parent[MB];
+  int jtype[MB];
+  unsigned long long anc[MB];   // bit j of anc[i]: j == i or j is an ancestor of i
+  T S[MB][6];
+  T X0[MB][36], Xs[MB][36], Xc[MB][36];
+  T I[MB][36];
+  T damping[MB];
+};
+
+GDEV void sincos_g(float x, float* s, float* c) { sincosf(x, s, c); }
+GDEV void sincos_g(double x, double* s, double* c) { sincos(x, s, c); }
+
+// (f1, f2) of X(q) = X0 + Xs f1 + Xc f2
+template <class T>
+GDEV void joint_fun(int jt, T q, T& f1, T& f2) {
+  if (jt == 0) {
+    sincos_g(q, &f1, &f2);
+  } else {
+    f1 = q;
+    f2 = T(0);
+  }
+}
+template <class T>
+GDEV void build_X(const DevModel<T>* __restrict__ m, int i, T f1, T f2, T (&X)[36]) {
+#pragma unroll
+  for (int k = 0; k < 36; ++k) X[k] = fma(m->Xc[i][k], f2, fma(m->Xs[i][k], f1, m->X0[i][k]));
+}
+template <class T>
+GDEV void mv(const T (&X)[36], const T* v, T (&o)[6]) {          // o = X v
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    T acc = X[r * 6] * v[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) acc = fma(X[r * 6 + c], v[c], acc);
+    o[r] = acc;
+  }
+}
+template <class T>
+GDEV void mtv(const T (&X)[36], const T* f, T (&o)[6]) {         // o = X^T f
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    T acc = X[c] * f[0];
+#pragma unroll
+    for (int r = 1; r < 6; ++r) acc = fma(X[r * 6 + c], f[r], acc);
+    o[c] = acc;
+  }
+}
+template <class T>
+GDEV void mvI(const DevModel<T>* __restrict__ m, int i, const T* v, T (&o)[6]) {   // o = I_i v
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    T acc = m->I[i][r * 6] * v[0];
+#pragma unroll
+    for (int c = 1; c < 6; ++c) acc = fma(m->I[i][r * 6 + c], v[c], acc);
+    o[r] = acc;
+  }
+}
+template <class T>
+GDEV void cross3g(const T* a, const T* b, T* o) {
+  o[0] = fma(a[1], b[2], -(a[2] * b[1]));
+  o[1] = fma(a[2], b[0], -(a[0] * b[2]));
+  o[2] = fma(a[0], b[1], -(a[1] * b[0]));
+}
+// o = crm(v) x   (cross_operator, RBDReference.py:9-21; mxS(S, v) = crm(v) S, :56-59)
+template <class T>
+GDEV void crm_mul(const T* v, const T* x, T (&o)[6]) {
+  T t0[3], t1[3], t2[3];
+  cross3g(v, x, t0);
+  cross3g(v + 3, x, t1);
+  cross3g(v, x + 3, t2);
+  o[0] = t0[0]; o[1] = t0[1]; o[2] = t0[2];
+  o[3] = t1[0] + t2[0]; o[4] = t1[1] + t2[1]; o[5] = t1[2] + t2[2];
+}
+// o = crf(v) f = -crm(v)^T f   (fxv, :149-164)
+template <class T>
+GDEV void crf_mul(const T* v, const T* f, T (&o)[6]) {
+  T t0[3], t1[3], t2[3];
+  cross3g(v, f, t0);
+  cross3g(v + 3, f + 3, t1);
+  cross3g(v, f + 3, t2);
+  o[0] = t0[0] + t1[0]; o[1] = t0[1] + t1[1]; o[2] = t0[2] + t1[2];
+  o[3] = t2[0]; o[4] = t2[1]; o[5] = t2[2];
+}
+template <class T>
+GDEV T dot6g(const T* a, const T* b) {
+  T acc = a[0] * b[0];
+#pragma unroll
+  for (int r = 1; r < 6; ++r) acc = fma(a[r], b[r], acc);
+  return acc;
+}
+
+template <class T, int NMAX>
+struct RneaState {
+  T v[NMAX][6], a[NMAX][6], f[NMAX][6];
+  T f1[NMAX], f2[NMAX], qd[NMAX];
+};
+
+// rnea_fpass + rnea_bpass of one configuration (:559-621); leaves v, a, the ACCUMULATED f, (f1, f2), qd in st.
+// vo / ao / fo / co: this configuration's output rows (nullable); v, a, f are [6][n].
+template <class T, int NMAX>
+GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, const T* qd, const T* qdd, T grav,
+                      RneaState<T, NMAX>& st, T* co, T* vo, T* ao, T* fo) {
+  for (int i = 0; i < n; ++i) {
+    T f1, f2;
+    joint_fun(m->jtype[i], q[i], f1, f2);
+    st.f1[i] = f1; st.f2[i] = f2;
+    const T qdi = qd[i];
+    st.qd[i] = qdi;
+    T X[36];
+    build_X(m, i, f1, f2, X);
+    const int p = m->parent[i];
+    T v[6], a[6];
+    if (p < 0) {                                            // v_p = 0, a_p = [0,0,0,0,0,-GRAVITY]  (:565-566, :576-581)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { v[r] = T(0); a[r] = X[r * 6 + 5] * (-grav); }
+    } else {
+      mv(X, st.v[p], v);
+      mv(X, st.a[p], a);
+    }
+    T S[6], vJ[6], t[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { S[r] = m->S[i][r]; vJ[r] = S[r] * qdi; v[r] += vJ[r]; }   // :586-587
+    crm_mul(v, vJ, t);                                                                      // :588
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r] += t[r];
+    if (qdd != nullptr) {
+      const T qddi = qdd[i];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a[r] = fma(S[r], qddi, a[r]);                             // :589-593
+    }
+    T Iv[6], Ia[6], w[6];
+    mvI(m, i, v, Iv);
+    mvI(m, i, a, Ia);
+    crf_mul(v, Iv, w);                                                                      // :595-596
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      st.v[i][r] = v[r]; st.a[i][r] = a[r]; st.f[i][r] = Ia[r] + w[r];
+      if (vo) vo[r * n + i] = v[r];
+      if (ao) ao[r * n + i] = a[r];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    T f[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) f[r] = st.f[i][r];
+    if (co) co[i] = dot6g(m->S[i], f);                                                      // :612
+    if (fo) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) fo[r * n + i] = f[r];
+    }
+    const int p = m->parent[i];
+    if (p >= 0) {
+      T X[36], t[6];
+      build_X(m, i, st.f1[i], st.f2[i], X);
+      mtv(X, f, t);                                                                         // :618-619
+#pragma unroll
+      for (int r = 0; r < 6; ++r) st.f[p][r] += t[r];
+    }
+  }
+}
+
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_rnea_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
+                                                    const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
+                                                    long long B, T* __restrict__ c, T* __restrict__ v,
+                                                    T* __restrict__ a, T* __restrict__ f) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  RneaState<T, NMAX> st;
+  rnea_config<T, NMAX>(m, n, q + b * n, qd + b * n, qdd ? qdd + b * n : nullptr, grav, st, c + b * n,
+                       v ? v + b * 6 * n : nullptr, a ? a + b * 6 * n : nullptr, f ? f + b * 6 * n : nullptr);
+}
+
+// df = I da + crf(dv)(I v) + crf(v)(I dv)   (:1179-1185, :1247-1252)
+template <class T>
+GDEV void df_of(const DevModel<T>* __restrict__ m, int i, const T* v, const T (&Iv)[6], const T (&dv)[6], const T (&da)[6],
+                T* out) {
+  T Ida[6], Idv[6], w1[6], w2[6];
+  mvI(m, i, da, Ida);
+  mvI(m, i, dv, Idv);
+  crf_mul(dv, Iv, w1);
+  crf_mul(v, Idv, w2);
+#pragma unroll
+  for (int r = 0; r < 6; ++r) out[r] = Ida[r] + w1[r] + w2[r];
+}
+
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
+                                                         const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
+                                                         int use_damping, long long B, T* __restrict__ c,
+                                                         T* __restrict__ dc) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  RneaState<T, NMAX> st;
+  rnea_config<T, NMAX>(m, n, q + b * n, qd + b * n, qdd ? qdd + b * n : nullptr, grav, st, c ? c + b * n : nullptr,
+                       (T*)nullptr, (T*)nullptr, (T*)nullptr);                               // :1353
+  T dvq[NMAX][6], daq[NMAX][6], dfq[NMAX][6], dvd[NMAX][6], dad[NMAX][6], dfd[NMAX][6];
+  T* row = dc + b * 2 * n * n;
+  for (int c0 = 0; c0 < n; ++c0) {
+    // ---- forward recursions of column c0 over subtree(c0) ----
+    for (int i = c0; i < n; ++i) {
+      if (!((m->anc[i] >> c0) & 1ull)) continue;
+      T X[36], S[6];
+      build_X(m, i, st.f1[i], st.f2[i], X);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+      const int p = m->parent[i];
+      const T qdi = st.qd[i];
+      T vq[6], aq[6], vd[6], ad[6], t[6];
+      if (i == c0) {
+        T xa[6];
+        if (p >= 0) {
+          T xv[6];
+          mv(X, st.v[p], xv);
+          crm_mul(xv, S, vq);                               // dv[:,i,i] += crm(X v_p) S     (:1157-1159)
+          mv(X, st.a[p], xa);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) { vq[r] = T(0); xa[r] = X[r * 6 + 5] * (-grav); }
+        }
+        crm_mul(vq, S, t);                                  // da[:,c,i] += qd_i crm(dv[:,c,i]) S   (:1164-1170)
+        crm_mul(xa, S, aq);                                 // da[:,i,i] += crm(X a_p) S            (:1172-1175)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) aq[r] = fma(qdi, t[r], aq[r]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) vd[r] = S[r];           // dv[:,i,i] += S                       (:1231)
+        crm_mul(vd, S, t);                                  // (:1235-1240)
+        crm_mul(st.v[i], S, ad);                            // da[:,i,i] += crm(v_i) S              (:1243)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ad[r] = fma(qdi, t[r], ad[r]);
+      } else {
+        mv(X, dvq[p], vq);                                  // (:1157, :1162-1163)
+        mv(X, daq[p], aq);
+        crm_mul(vq, S, t);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) aq[r] = fma(qdi, t[r], aq[r]);
+        mv(X, dvd[p], vd);                                  // (:1229-1234)
+        mv(X, dad[p], ad);
+        crm_mul(vd, S, t);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ad[r] = fma(qdi, t[r], ad[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { dvq[i][r] = vq[r]; daq[i][r] = aq[r]; dvd[i][r] = vd[r]; dad[i][r] = ad[r]; }
+      T Iv[6];
+      mvI(m, i, st.v[i], Iv);
+      df_of(m, i, st.v[i], Iv, vq, aq, dfq[i]);
+      df_of(m, i, st.v[i], Iv, vd, ad, dfd[i]);
+    }
+    for (int x = m->parent[c0]; x >= 0; x = m->parent[x]) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { dfq[x][r] = T(0); dfd[x][r] = T(0); }
+    }
+    // ---- backward sweep of column c0 over subtree(c0) and the ancestors of c0 ----
+    for (int i = n - 1; i >= 0; --i) {
+      const bool rel = (((m->anc[i] >> c0) & 1ull) != 0) || (((m->anc[c0] >> i) & 1ull) != 0);
+      T eq = T(0), ed = T(0);
+      if (rel) {
+        T gq[6], gd[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { gq[r] = dfq[i][r]; gd[r] = dfd[i][r]; }
+        eq = dot6g(m->S[i], gq);                            // dc_dq[i,:] = S^T df[:,:,i]   (:1284)
+        ed = dot6g(m->S[i], gd);                            // (:1325)
+        if (i == c0 && use_damping) ed += m->damping[i];    // (:1336-1341)
+        const int p = m->parent[i];
+        if (p >= 0) {
+          T X[36], t[6];
+          build_X(m, i, st.f1[i], st.f2[i], X);
+          if (i == c0) {                                    // df[:,i,p] += X^T fxS(S, f_i), fxS = -crm(f_i) S  (:1292-1294)
+            T g[6];
+            crm_mul(st.f[i], m->S[i], g);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) gq[r] -= g[r];
+          }
+          mtv(X, gq, t);                                    // df[:,:,p] += X^T df[:,:,i]   (:1291)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) dfq[p][r] += t[r];
+          mtv(X, gd, t);                                    // (:1331)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) dfd[p][r] += t[r];
+        }
+      }
+      row[i * 2 * n + c0] = eq;
+      row[i * 2 * n + n + c0] = ed;
+    }
+  }
+}
+
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, long long B,
+                                                    int dense, T* __restrict__ Minv) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T IA[NMAX][36];
+  T U[NMAX][6], Di[NMAX], f1[NMAX], f2[NMAX];
+  for (int i = 0; i < n; ++i) {
+    joint_fun(m->jtype[i], q[b * n + i], f1[i], f2[i]);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) IA[i][k] = m->I[i][k];      // IA = deepcopy(I)   (:662)
+  }
+  // articulated inertias (:697-700, :728-733)
+  for (int i = n - 1; i >= 0; --i) {
+    T A[36], u[6], S[6];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] = IA[i][k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+    mv(A, S, u);
+    const T D = dot6g(S, u);
+    const T di = T(1) / D;
+    Di[i] = di;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) U[i][r] = u[r];
+    const int p = m->parent[i];
+    if (p >= 0) {
+      T X[36];
+      build_X(m, i, f1[i], f2[i], X);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) A[r * 6 + cc] = fma(-(u[r] * di), u[cc], A[r * 6 + cc]);   // Ia = IA - U U^T / D
+      T W[36];                                               // W = Ia X
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          T acc = A[r * 6] * X[cc];
+#pragma unroll
+          for (int k = 1; k < 6; ++k) acc = fma(A[r * 6 + k], X[k * 6 + cc], acc);
+          W[r * 6 + cc] = acc;
+        }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {                     // IA_p += X^T W
+          T acc = X[r] * W[cc];
+#pragma unroll
+          for (int k = 1; k < 6; ++k) acc = fma(X[k * 6 + r], W[k * 6 + cc], acc);
+          IA[p][r * 6 + cc] += acc;
+        }
+    }
+  }
+  T Mc[NMAX], F[NMAX][6];
+  T* out = Minv + b * n * n;
+  for (int c0 = 0; c0 < n; ++c0) {
+    for (int i = 0; i <= c0; ++i) Mc[i] = T(0);
+    {                                                        // backward sweep of column c0: its root path (:700-726)
+      T Fv[6];
+      const T m0 = Di[c0];
+      Mc[c0] = m0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Fv[r] = U[c0][r] * m0;
+      for (int i = c0, p = m->parent[c0]; p >= 0; i = p, p = m->parent[p]) {
+        T X[36], Fp[6];
+        build_X(m, i, f1[i], f2[i], X);
+        mtv(X, Fv, Fp);
+        const T mp = -(Di[p] * dot6g(m->S[p], Fp));
+        Mc[p] = mp;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Fv[r] = fma(U[p][r], mp, Fp[r]);
+      }
+    }
+    for (int i = 0; i <= c0; ++i) {                          // forward sweep, rows <= c0 (:771-781)
+      const int p = m->parent[i];
+      T mm = Mc[i];
+      if (p >= 0) {
+        T X[36], xf[6], Fp[6], Ui[6];
+        build_X(m, i, f1[i], f2[i], X);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { Fp[r] = F[p][r]; Ui[r] = U[i][r]; }
+        mv(X, Fp, xf);
+        mm = fma(-Di[i], dot6g(Ui, xf), mm);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) F[i][r] = fma(m->S[i][r], mm, xf[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) F[i][r] = m->S[i][r] * mm;
+      }
+      out[i * n + c0] = mm;
+      if (i != c0) out[c0 * n + i] = dense ? mm : T(0);      // (:799-804)
+    }
+  }
+}
+
+// qdd = Minv (u - c)   (:1371-1374): one thread per (configuration, row)
+template <class T>
+__global__ void __launch_bounds__(256) g_fd_apply_kernel(int n, long long B, const T* __restrict__ Minv,
+                                                         const T* __restrict__ u, const T* __restrict__ c,
+                                                         T* __restrict__ qdd) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * n) return;
+  const long long b = idx / n;
+  const T* Mr = Minv + idx * n;
+  T acc = T(0);
+  for (int j = 0; j < n; ++j) acc = fma(Mr[j], u[b * n + j] - c[b * n + j], acc);
+  qdd[idx] = acc;
+}
+// out = -Minv dc   (:1383-1384): one thread per output element
+template <class T>
+__global__ void __launch_bounds__(256) g_neg_mm_kernel(int n, long long B, const T* __restrict__ Minv,
+                                                       const T* __restrict__ dc, T* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = 2LL * n * n;
+  if (idx >= B * per) return;
+  const long long b = idx / per;
+  const int rem = (int)(idx - b * per);
+  const int i = rem / (2 * n), k = rem - i * 2 * n;
+  const T* Mr = Minv + (b * n + i) * n;
+  const T* D = dc + b * per + k;
+  T acc = T(0);
+  for (int j = 0; j < n; ++j) acc = fma(Mr[j], D[j * 2 * n], acc);
+  out[idx] = -acc;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+char* err_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  snprintf(err_buf(), 512, "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+
+}  // namespace rbdg
+
+struct rbd_model {
+  int device;
+  int n;
+  rbdg::DevModel<float>* d32;
+  rbdg::DevModel<double>* d64;
+};
+
+namespace rbdg {
+
+template <class T>
+const DevModel<T>* dev_of(const rbd_model* m);
+template <>
+const DevModel<float>* dev_of<float>(const rbd_model* m) { return m->d32; }
+template <>
+const DevModel<double>* dev_of<double>(const rbd_model* m) { return m->d64; }
+
+template <class T>
+void fill(DevModel<T>& d, const rbd_model_desc* s) {
+  std::memset(&d, 0, sizeof(d));
+  d.n = s->n;
+  for (int i = 0; i < s->n; ++i) {
+    d.parent[i] = s->parent[i];
+    d.jtype[i] = s->joint_type[i];
+    d.anc[i] = (1ull << i) | (s->parent[i] >= 0 ? d.anc[s->parent[i]] : 0ull);
+    for (int r = 0; r < 6; ++r) d.S[i][r] = (T)s->S[i * 6 + r];
+    for (int k = 0; k < 36; ++k) {
+      d.X0[i][k] = (T)s->X0[i * 36 + k];
+      d.Xs[i][k] = (T)s->Xs[i * 36 + k];
+      d.Xc[i][k] = s->joint_type[i] == 0 ? (T)s->Xc[i * 36 + k] : T(0);
+      d.I[i][k] = (T)s->I[i * 36 + k];
+    }
+    d.damping[i] = (T)s->damping[i];
+  }
+}
+
+int check_call(const rbd_model* m, long long B, const char* who) {
+  if (m == nullptr) return fail(RBD_G_ERR_ARG, "%s: null model", who);
+  if (B < 0) return fail(RBD_G_ERR_ARG, "%s: B = %lld", who, B);
+  if (B > (1LL << 31) * 64 - 64) return fail(RBD_G_ERR_ARG, "%s: B = %lld exceeds the grid", who, B);
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, who);
+  if (dev != m->device) return fail(RBD_G_ERR_ARG, "%s: the model lives on device %d, the current device is %d", who, m->device, dev);
+  return 0;
+}
+
+#define RBDG_DISPATCH(n, CALL)             \
+  do {                                     \
+    if ((n) <= 8) { CALL(8); }             \
+    else if ((n) <= 16) { CALL(16); }      \
+    else if ((n) <= 32) { CALL(32); }      \
+    else { CALL(64); }                     \
+  } while (0)
+
+template <class T>
+int rnea_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav, long long B, T* c, T* v, T* a, T* f, void* stream) {
+  if (int rc = check_call(m, B, "rbd_g_rnea")) return rc;
+  if (!q || !qd || !c) return fail(RBD_G_ERR_ARG, "rbd_g_rnea: q, qd, c must not be null");
+  if (B == 0) return 0;
+  const unsigned grid = (unsigned)((B + 63) / 64);
+#define CALL(NM) hipLaunchKernelGGL((g_rnea_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f)
+  RBDG_DISPATCH(m->n, CALL);
+#undef CALL
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea launch");
+}
+template <class T>
+int grad_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav, int damp, long long B, T* c, T* dc, void* stream) {
+  if (int rc = check_call(m, B, "rbd_g_rnea_grad")) return rc;
+  if (!q || !qd || !dc) return fail(RBD_G_ERR_ARG, "rbd_g_rnea_grad: q, qd, dc_du must not be null");
+  if (B == 0) return 0;
+  const unsigned grid = (unsigned)((B + 63) / 64);
+#define CALL(NM) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
+  RBDG_DISPATCH(m->n, CALL);
+#undef CALL
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea_grad launch");
+}
+template <class T>
+int minv_host(const rbd_model* m, const T* q, long long B, int dense, T* Minv, void* stream) {
+  if (int rc = check_call(m, B, "rbd_g_minv")) return rc;
+  if (!q || !Minv) return fail(RBD_G_ERR_ARG, "rbd_g_minv: q, Minv must not be null");
+  if (B == 0) return 0;
+  const unsigned grid = (unsigned)((B + 63) / 64);
+#define CALL(NM) hipLaunchKernelGGL((g_minv_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv)
+  RBDG_DISPATCH(m->n, CALL);
+#undef CALL
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_minv launch");
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t fd_ws(int n, long long B, int esz, int grad) {
+  if (B <= 0) return 0;
+  size_t s = align256((size_t)B * n * esz) + align256((size_t)B * n * n * esz);
+  if (grad) s += align256((size_t)B * 2 * n * n * esz);
+  return s;
+}
+template <class T>
+int fd_host(const rbd_model* m, const T* q, const T* qd, const T* u, T grav, long long B, T* qdd, T* dout, bool grad,
+            void* ws, size_t wsb, void* stream) {
+  const char* who = grad ? "rbd_g_forward_dynamics_grad" : "rbd_g_forward_dynamics";
+  if (int rc = check_call(m, B, who)) return rc;
+  if (!q || !qd || !u || !qdd || (grad && !dout)) return fail(RBD_G_ERR_ARG, "%s: null argument", who);
+  if (B == 0) return 0;
+  const int n = m->n;
+  const size_t need = fd_ws(n, B, (int)sizeof(T), grad ? 1 : 0);
+  if (!ws || wsb < need) return fail(RBD_G_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, wsb);
+  char* w = (char*)ws;
+  T* c = (T*)w;
+  T* Mi = (T*)(w + align256((size_t)B * n * sizeof(T)));
+  T* dc = (T*)((char*)Mi + align256((size_t)B * n * n * sizeof(T)));
+  if (int rc = rnea_host<T>(m, q, qd, nullptr, grav, B, c, nullptr, nullptr, nullptr, stream)) return rc;   // c(q, qd)  (:1372)
+  if (int rc = minv_host<T>(m, q, B, 1, Mi, stream)) return rc;                                              // (:1373)
+  {
+    const long long tot = B * n;
+    hipLaunchKernelGGL((g_fd_apply_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, B, Mi, u, c, qdd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, who);
+  }
+  if (!grad) return 0;
+  if (int rc = grad_host<T>(m, q, qd, qdd, grav, 0, B, nullptr, dc, stream)) return rc;                      // (:1380)
+  {
+    const long long tot = B * 2LL * n * n;
+    hipLaunchKernelGGL((g_neg_mm_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, B, Mi, dc, dout);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, who);
+  }
+  return 0;
+}
+
+}  // namespace rbdg
+
+extern "C" {
+
+int rbd_g_abi_version(void) { return RBD_G_ABI_VERSION; }
+const char* rbd_g_last_error(void) { return rbdg::err_buf(); }
+
+int rbd_model_create(const rbd_model_desc* s, int device, rbd_model** out) {
+  using namespace rbdg;
+  if (!s || !out) return fail(RBD_G_ERR_ARG, "rbd_model_create: null argument");
+  *out = nullptr;
+  if (s->abi_version != RBD_G_ABI_VERSION) return fail(RBD_G_ERR_ARG, "rbd_model_create: abi_version %d, library has %d", s->abi_version, RBD_G_ABI_VERSION);
+  if (s->n < 1 || s->n > MB) return fail(RBD_G_ERR_UNSUPPORTED, "rbd_model_create: n = %d, supported 1..%d", s->n, MB);
+  if (!s->parent || !s->joint_type || !s->S || !s->X0 || !s->Xs || !s->Xc || !s->I || !s->damping)
+    return fail(RBD_G_ERR_ARG, "rbd_model_create: null array in the description");
+  for (int i = 0; i < s->n; ++i) {
+    if (s->parent[i] < -1 || s->parent[i] >= i) return fail(RBD_G_ERR_ARG, "rbd_model_create: parent[%d] = %d must be -1 or precede the body", i, s->parent[i]);
+    if (s->joint_type[i] != 0 && s->joint_type[i] != 1) return fail(RBD_G_ERR_UNSUPPORTED, "rbd_model_create: joint_type[%d] = %d", i, s->joint_type[i]);
+    bool ok = std::isfinite(s->damping[i]);
+    for (int r = 0; r < 6; ++r) ok = ok && std::isfinite(s->S[i * 6 + r]);
+    for (int k = 0; k < 36; ++k)
+      ok = ok && std::isfinite(s->X0[i * 36 + k]) && std::isfinite(s->Xs[i * 36 + k]) && std::isfinite(s->Xc[i * 36 + k]) && std::isfinite(s->I[i * 36 + k]);
+    if (!ok) return fail(RBD_G_ERR_ARG, "rbd_model_create: body %d has a non-finite constant", i);
+  }
+  int prev = -1;
+  hipError_t e = hipGetDevice(&prev);
+  if (e != hipSuccess) return hip_fail(e, "rbd_model_create");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(e, "rbd_model_create: hipSetDevice");
+  rbd_model* m = new (std::nothrow) rbd_model{device, s->n, nullptr, nullptr};
+  DevModel<float>* h32 = new (std::nothrow) DevModel<float>;
+  DevModel<double>* h64 = new (std::nothrow) DevModel<double>;
+  int rc = 0;
+  if (!m || !h32 || !h64) rc = fail(RBD_G_ERR_ARG, "rbd_model_create: out of host memory");
+  if (rc == 0) {
+    fill(*h32, s);
+    fill(*h64, s);
+    if ((e = hipMalloc((void**)&m->d32, sizeof(*h32))) != hipSuccess || (e = hipMalloc((void**)&m->d64, sizeof(*h64))) != hipSuccess ||
+        (e = hipMemcpy(m->d32, h32, sizeof(*h32), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(m->d64, h64, sizeof(*h64), hipMemcpyHostToDevice)) != hipSuccess)
+      rc = hip_fail(e, "rbd_model_create: upload");
+  }
+  delete h32;
+  delete h64;
+  if (rc != 0 && m) {
+    if (m->d32) (void)hipFree(m->d32);
+    if (m->d64) (void)hipFree(m->d64);
+    delete m;
+    m = nullptr;
+  }
+  (void)hipSetDevice(prev);
+  *out = m;
+  return rc;
+}
+void rbd_model_destroy(rbd_model* m) {
+  if (!m) return;
+  int prev = -1;
+  if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(m->device) == hipSuccess) {
+    (void)hipFree(m->d32);
+    (void)hipFree(m->d64);
+    (void)hipSetDevice(prev);
+  }
+  delete m;
+}
+int rbd_model_n(const rbd_model* m) { return m ? m->n : 0; }
+
+int rbd_g_rnea_f32(const rbd_model* m, const float* q, const float* qd, const float* qdd, float g, int64_t B, float* c, float* v, float* a, float* f, void* st) {
+  return rbdg::rnea_host<float>(m, q, qd, qdd, g, B, c, v, a, f, st);
+}
+int rbd_g_rnea_f64(const rbd_model* m, const double* q, const double* qd, const double* qdd, double g, int64_t B, double* c, double* v, double* a, double* f, void* st) {
+  return rbdg::rnea_host<double>(m, q, qd, qdd, g, B, c, v, a, f, st);
+}
+int rbd_g_rnea_grad_f32(const rbd_model* m, const float* q, const float* qd, const float* qdd, float g, int damp, int64_t B, float* c, float* dc, void* st) {
+  return rbdg::grad_host<float>(m, q, qd, qdd, g, damp, B, c, dc, st);
+}
+int rbd_g_rnea_grad_f64(const rbd_model* m, const double* q, const double* qd, const double* qdd, double g, int damp, int64_t B, double* c, double* dc, void* st) {
+  return rbdg::grad_host<double>(m, q, qd, qdd, g, damp, B, c, dc, st);
+}
+int rbd_g_minv_f32(const rbd_model* m, const float* q, int64_t B, int dense, float* Mi, void* st) { return rbdg::minv_host<float>(m, q, B, dense, Mi, st); }
+int rbd_g_minv_f64(const rbd_model* m, const double* q, int64_t B, int dense, double* Mi, void* st) { return rbdg::minv_host<double>(m, q, B, dense, Mi, st); }
+
+size_t rbd_g_fd_workspace_bytes(const rbd_model* m, int64_t B, int elem_size, int with_grad) {
+  if (!m || (elem_size != 4 && elem_size != 8)) return 0;
+  return rbdg::fd_ws(m->n, B, elem_size, with_grad);
+}
+int rbd_g_forward_dynamics_f32(const rbd_model* m, const float* q, const float* qd, const float* u, float g, int64_t B, float* qdd, void* ws, size_t wsb, void* st) {
+  return rbdg::fd_host<float>(m, q, qd, u, g, B, qdd, nullptr, false, ws, wsb, st);
+}
+int rbd_g_forward_dynamics_f64(const rbd_model* m, const double* q, const double* qd, const double* u, double g, int64_t B, double* qdd, void* ws, size_t wsb, void* st) {
+  return rbdg::fd_host<double>(m, q, qd, u, g, B, qdd, nullptr, false, ws, wsb, st);
+}
+int rbd_g_forward_dynamics_grad_f32(const rbd_model* m, const float* q, const float* qd, const float* u, float g, int64_t B, float* qdd, float* d, void* ws, size_t wsb, void* st) {
+  return rbdg::fd_host<float>(m, q, qd, u, g, B, qdd, d, true, ws, wsb, st);
+}
+int rbd_g_forward_dynamics_grad_f64(const rbd_model* m, const double* q, const double* qd, const double* u, double g, int64_t B, double* qdd, double* d, void* ws, size_t wsb, void* st) {
+  return rbdg::fd_host<double>(m, q, qd, u, g, B, qdd, d, true, ws, wsb, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+"""GPU parity of the MODEL-HANDLE library (include/rbd_generic.h, librbd_generic.so; run with ``-m gpu``).
+
+Same checkers as tests/test_gpu_parity.py -- the golden vectors generated from the real reference
+(oracle/gen_golden.py) and, for ragged batches, the CPU oracle -- same tolerances (normwise per row: 1e-5 in fp32,
+1e-11 in fp64); every call goes through ctypes into ``rbd_model_create`` / ``rbd_g_*`` with
+``RBDReference(robot, build=False, generic="only")``: no per-robot library is loaded by these objects."""
+import numpy as np
+import pytest
+
+from conftest import all_golden_names, load_golden, make_robot
+from test_gpu_parity import TOL32, TOL64, _torch, check, check_conditioned, dev_tensors
+
+pytestmark = pytest.mark.gpu
+
+_G = {}
+
+
+def generic_for(name):
+    if name not in _G:
+        from rbdreference_amd import RBDReference
+        _G[name] = RBDReference(make_robot(name), build=False, generic="only")
+    return _G[name]
+
+
+@pytest.fixture(params=["float32", "float64"])
+def prec(request):
+    torch = _torch()
+    return (torch.float32, TOL32) if request.param == "float32" else (torch.float64, TOL64)
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_generic_rnea_and_gradient_vs_golden(name, prec):
+    """rbd_g_rnea / rbd_g_rnea_grad against the reference's outputs (RBDReference.py:623-628, :1345-1368): every
+    fixed-base fixture, incl. the prismatic robot (the literal fxS term, :1292-1294), qdd=None and damping."""
+    from rbdreference_amd._lib import RBD_OP_RNEA_GRAD
+    dt, tol = prec
+    g = load_golden(name); rbd = generic_for(name)
+    assert rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, 16).startswith("g_rnea_grad_kernel<")
+    q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    c, v, a, f = rbd.rnea(q, qd, qdd)
+    assert rbd._lib.served_by_generic()
+    check("c", c, g["c"], tol); check("v", v, g["fpass_v"], tol); check("a", a, g["fpass_a"], tol)
+    check("f (accumulated)", f, g["f_acc"], tol)
+    check("c_noqdd", rbd.rnea(q, qd)[0], g["c_noqdd"], tol)
+    check("c only", rbd.rnea(q, qd, qdd, outputs="c")[0], g["c"], tol)
+    c, dc = rbd.rnea_grad(q, qd, qdd, return_c=True)
+    check("dc_du", dc, g["dc_du"], tol); check("c", c, g["c"], tol)
+    check("dc_du_damped", rbd.rnea_grad(q, qd, qdd, USE_VELOCITY_DAMPING=True), g["dc_du_damped"], tol)
+    check("dc_du_noqdd", rbd.rnea_grad(q, qd), g["dc_du_noqdd"], tol)
+    c2, v, a, f, dc2 = rbd.rnea_and_grad(q, qd, qdd)
+    check("c", c2, g["c"], tol); check("v", v, g["fpass_v"], tol); check("f (accumulated)", f, g["f_acc"], tol)
+    check("dc_du", dc2, g["dc_du"], tol)
+
+
+@pytest.mark.parametrize("name", all_golden_names())
+def test_generic_minv_and_forward_dynamics_vs_golden(name, prec):
+    """rbd_g_minv (:785-806) and rbd_g_forward_dynamics(_grad) (:1371-1384) against the reference's outputs."""
+    dt, tol = prec
+    torch = _torch()
+    g = load_golden(name); rbd = generic_for(name)
+    q, qd, u = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    check("Minv_dense", rbd.minv(q), g["Minv_dense"], tol)
+    assert rbd._lib.served_by_generic()
+    up = rbd.minv(q, output_dense=False)
+    check("Minv_upper", up, np.triu(g["Minv_upper"]), tol)
+    il = np.tril_indices(rbd.n, -1)
+    assert float(np.abs(up.double().cpu().numpy()[:, il[0], il[1]]).max(initial=0.0)) == 0.0
+    if dt == torch.float32:
+        check_conditioned("fd_qdd", rbd.forward_dynamics(q, qd, u), g["fd_qdd"], g["H"])
+        a, b = rbd.forward_dynamics_grad(q, qd, u)
+        check_conditioned("fd_dq", a.contiguous(), g["fd_dq"], g["H"])
+        check_conditioned("fd_dqd", b.contiguous(), g["fd_dqd"], g["H"])
+    else:
+        check("fd_qdd", rbd.forward_dynamics(q, qd, u), g["fd_qdd"], 1e-9)
+        a, b = rbd.forward_dynamics_grad(q, qd, u)
+        check("fd_dq", a.contiguous(), g["fd_dq"], 1e-9); check("fd_dqd", b.contiguous(), g["fd_dqd"], 1e-9)
+
+
+@pytest.mark.parametrize("name", ["iiwa_like", "atlas_like", "random_prismatic_n6"])
+@pytest.mark.parametrize("B", [1, 63, 65, 1000])
+def test_generic_ragged_batches_vs_oracle(name, B):
+    """Batches that do not fill a wave, against the CPU oracle on the same seeded inputs (fp32)."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    rbd = generic_for(name); om = orc.model_from_robot(make_robot(name))
+    rng = np.random.default_rng(100 + B)
+    n = rbd.n
+    q = rng.uniform(-np.pi, np.pi, (B, n)); qd = rng.uniform(-1, 1, (B, n)); qdd = rng.uniform(-1, 1, (B, n))
+    tq, tqd, tqdd = dev_tensors(torch.float32, q, qd, qdd)
+    q32, qd32, qdd32 = (x.astype(np.float32).astype(np.float64) for x in (q, qd, qdd))
+    c, v, a, f = orc.rnea(om, q32, qd32, qdd32)
+    gc, gv, ga, gf = rbd.rnea(tq, tqd, tqdd)
+    check("c", gc, c, TOL32); check("f", gf, f, TOL32)
+    check("dc_du", rbd.rnea_grad(tq, tqd, tqdd), orc.rnea_grad(om, q32, qd32, qdd32), TOL32)
+    check("Minv", rbd.minv(tq), orc.minv(om, q32), TOL32)
+
+
+def test_generic_equals_the_specialised_library_to_rounding_at_full_size():
+    """configs[3]'s shape through both libraries (B = 131 072 rows of the 7-DoF arm, fp32): the model-handle kernels
+    and the robot's own kernels agree row by row to the fp32 tolerance (they are different evaluation orders of the
+    same recursion, so not bit for bit), and the generic path's time is printed next to the specialised one."""
+    torch = _torch()
+    from rbdreference_amd import RBDReference
+    B = 131072
+    spec = RBDReference(make_robot("iiwa_like"), build=False, generic="never"); gen = generic_for("iiwa_like")
+    rng = np.random.default_rng(77)
+    q, qd, qdd = dev_tensors(torch.float32, rng.uniform(-np.pi, np.pi, (B, 7)), rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, 7)))
+    out = {}
+    for nm, r in (("specialised", spec), ("generic", gen)):
+        r.rnea_grad(q, qd, qdd); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dc = r.rnea_grad(q, qd, qdd)
+        e1.record(); torch.cuda.synchronize()
+        out[nm] = (dc, e0.elapsed_time(e1) / 5 * 1e3, r.minv(q))
+    check("dc_du generic vs specialised", out["generic"][0], out["specialised"][0].double().cpu().numpy(), 2 * TOL32)
+    check("Minv generic vs specialised", out["generic"][2], out["specialised"][2].double().cpu().numpy(), 2 * TOL32)
+    print(f"\nrnea_grad iiwa B={B} fp32: specialised {out['specialised'][1]:.1f} us, generic {out['generic'][1]:.1f} us")
+
+
+def test_generic_argument_errors_and_handle_lifetime():
+    """C-ABI argument checks of the model-handle library, called directly through ctypes."""
+    import ctypes
+    torch = _torch()
+    from rbdreference_amd.generic import GenericModel
+    from rbdreference_amd import pack_robot
+    gm = GenericModel(pack_robot(make_robot("iiwa_like")))
+    h = gm.handle(0)
+    lib = gm.lib
+    assert lib.rbd_model_n(h) == 7 and gm.handle(0) == h
+    q = torch.zeros((4, 7), device="cuda:0")
+    assert lib.rbd_g_rnea_f32(h, q.data_ptr(), q.data_ptr(), None, -9.81, 4, None, None, None, None, None) == -1
+    assert b"must not be null" in lib.rbd_g_last_error()
+    assert lib.rbd_g_rnea_f32(None, q.data_ptr(), q.data_ptr(), None, -9.81, 4, q.data_ptr(), None, None, None, None) == -1
+    assert lib.rbd_g_minv_f32(h, q.data_ptr(), -1, 1, q.data_ptr(), None) == -1
+    assert lib.rbd_g_minv_f32(h, q.data_ptr(), 0, 1, q.data_ptr(), None) == 0            # empty batch: nothing to do
+    qdd = torch.empty((4, 7), device="cuda:0")
+    assert lib.rbd_g_forward_dynamics_f32(h, q.data_ptr(), q.data_ptr(), q.data_ptr(), -9.81, 4, qdd.data_ptr(), None, 0, None) == -3
+    assert b"workspace" in lib.rbd_g_last_error()
+    assert lib.rbd_g_fd_workspace_bytes(h, 4, 4, 0) > 0 and lib.rbd_g_fd_workspace_bytes(h, 4, 4, 1) > lib.rbd_g_fd_workspace_bytes(h, 4, 4, 0)
+    gm.close()
+    assert not gm._handles

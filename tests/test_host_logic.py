@@ -256,7 +256,7 @@ def test_lazy_library_serves_families_first_and_the_full_library_when_it_is_read
     from rbdreference_amd.build import full_library_ready
     m = _fresh_robot("first_use_probe_n2", [-1, 0], 4243)
     t0 = time.time()
-    L = RbdLibrary(m, build=True, lazy=True)
+    L = RbdLibrary(m, build=True, lazy=True, generic="never")
     assert time.time() - t0 < 2.0 and L._full is None and L._bg is not None
     f = L.fn("rbd_rnea", "f32")
     assert f is not None and (("rnea", "f32") in L._fams or L._full is not None)
@@ -265,3 +265,61 @@ def test_lazy_library_serves_families_first_and_the_full_library_when_it_is_read
     assert full_library_ready(m) and full.rbd_get_option(RBD_OPT_GRAD_KERNEL) == 3
     assert L.fn("rbd_rnea", "f32") is not None and L._tls.lib is full
     assert L.info.n == 2
+
+
+def test_generic_library_loads_exports_its_header_and_serves_a_never_built_robot_at_once():
+    """VERDICT r2 'missing 3' (a robot without hipcc and without minutes of compile): the model-handle library of
+    include/rbd_generic.h is built ONCE, exports every symbol the header declares, refuses bad descriptions on the
+    host (no GPU here), and RbdLibrary hands its entry points out for a never-built robot while the robot's own
+    library builds in the background; entry points it does not have still come from a family library."""
+    import ctypes
+    import re
+    import time
+    from rbdreference_amd._lib import RbdLibrary
+    from rbdreference_amd.build import build_generic, generic_library_ready
+    from rbdreference_amd.generic import (GENERIC_EXPORTED_SYMBOLS, GenericModel, RbdModelDesc, load_generic_library,
+                                          model_desc_arrays)
+    path = build_generic()
+    assert generic_library_ready() and os.path.exists(path)
+    lib = load_generic_library()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rbd_generic.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(rbd_(?:g_|model_)[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(GENERIC_EXPORTED_SYMBOLS), declared ^ set(GENERIC_EXPORTED_SYMBOLS)
+    for sym in GENERIC_EXPORTED_SYMBOLS:
+        assert hasattr(lib, sym), sym
+    # host-side validation of a description (nothing touches a GPU before the checks pass)
+    out = ctypes.c_void_p()
+    assert lib.rbd_model_create(None, 0, ctypes.byref(out)) == -1
+    m = _fresh_robot("generic_probe_n3", [-1, 0, 0], 4244)
+    a = model_desc_arrays(m)
+    assert a["X0"].shape == (3, 6, 6) and a["S"][0].sum() == 1.0
+    from rbdreference_amd.packer import _joint_X
+    for i in range(3):                                   # the three matrices reproduce the joint transform exactly
+        for q in (0.3, -1.7):
+            want = _joint_X(m.jtype[i], m.axis[i], q) @ m.Xtree[i]
+            f1, f2 = (np.sin(q), np.cos(q)) if m.jtype[i] == 0 else (q, 0.0)
+            np.testing.assert_allclose(a["X0"][i] + a["Xs"][i] * f1 + a["Xc"][i] * f2, want, rtol=0, atol=1e-15)
+    bad = a["parent"].copy(); bad[1] = 2
+    d = RbdModelDesc(1, 3, bad.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), a["joint_type"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                     *[a[k].ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for k in ("S", "X0", "Xs", "Xc", "I", "damping")])
+    assert lib.rbd_model_create(ctypes.byref(d), 0, ctypes.byref(out)) == -1 and b"parent[1]" in lib.rbd_g_last_error()
+    d.abi_version = 99
+    assert lib.rbd_model_create(ctypes.byref(d), 0, ctypes.byref(out)) == -1 and b"abi_version" in lib.rbd_g_last_error()
+    # the lazy library: generic first for what it serves, a family library for the rest, the full one when it is ready
+    t0 = time.time()
+    L = RbdLibrary(m, build=True, lazy=True, generic="auto")
+    assert time.time() - t0 < 2.0 and L._full is None
+    f = L.fn("rbd_rnea_grad", "f32")
+    assert f is not None and (L.served_by_generic() or L._full is not None)
+    assert L.kernel_name(1, 4, 1 << 20).startswith(("g_rnea_grad_kernel<float, 8>", "rnea_grad_"))
+    assert isinstance(L._generic, GenericModel) and not L._fams
+    L.fn("rbd_crba", "f32")                               # not served by the model-handle library
+    assert ("minv", "f32") in L._fams or L._full is not None
+    L.wait_specialized()
+    L.fn("rbd_rnea_grad", "f32")
+    assert not L.served_by_generic()
+    only = RbdLibrary(m, build=True, generic="only")
+    only.fn("rbd_minv", "f64")
+    assert only.served_by_generic() and only.get_option(0) == 0
+    with pytest.raises(Exception, match="not served by the model-handle library"):
+        only.fn("rbd_aba", "f32")
