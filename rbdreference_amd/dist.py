@@ -117,7 +117,9 @@ class ShardedRBD:
 
     Shards are evaluated under ``rbd.shard_of(B)``: kernel selection sees the GLOBAL batch size, so the rows a
     rank returns are bit-identical to the same rows of an unsharded call whatever the number of ranks (without it
-    a 65 536-row batch over 8 ranks would put 8 192-row shards on the small-batch column kernel)."""
+    a 65 536-row batch over 8 ranks would put 8 192-row shards on the small-batch column kernel).  For the same
+    reason the constructor waits for the robot's own full library (``RbdLibrary.wait_specialized``): ranks must not
+    mix the model-handle library's kernels (first-use path, equal to rounding only) with the specialised ones."""
 
     def __init__(self, rbd=None, group=None, compute_rnea_grad: Optional[Callable] = None,
                  compute_minv: Optional[Callable] = None, model_hash: Optional[str] = None):
@@ -126,6 +128,9 @@ class ShardedRBD:
         self._grad = compute_rnea_grad or (lambda q, qd, qdd, **kw: rbd.rnea_grad(q, qd, qdd, **kw))
         self._minv = compute_minv or (lambda q, **kw: rbd.minv(q, **kw))
         self._pin = rbd.shard_of if (rbd is not None and hasattr(rbd, "shard_of")) else (lambda B: contextlib.nullcontext())
+        lib = getattr(rbd, "_lib", None)
+        if lib is not None and hasattr(lib, "wait_specialized"):
+            lib.wait_specialized()
         check_same_model(model_hash or (rbd.model.hash if rbd is not None else ""), group)
 
     def local_slice(self, B: int) -> slice:
