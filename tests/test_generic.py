@@ -95,6 +95,35 @@ def test_generic_ragged_batches_vs_oracle(name, B):
     check("Minv", rbd.minv(tq), orc.minv(om, q32), TOL32)
 
 
+@pytest.mark.parametrize("n,prismatic_every", [(40, 0), (64, 7), (1, 0)])
+def test_generic_serves_robots_nobody_compiled_for(n, prismatic_every):
+    """What the model-handle library is for: robots with no library of their own -- a 40-body tree, the 64-body maximum
+    with prismatic joints mixed in (the NMAX = 64 kernels, 29 KB of private memory per lane in fp64), a single body --
+    against the CPU oracle, fp64 and fp32."""
+    from oracle import rbd_oracle as orc
+    from rbdreference_amd import RBDReference
+    from rbdreference_amd.robot import random_tree
+    torch = _torch()
+    rng = np.random.default_rng(n)
+    parents = [-1] + [int(rng.integers(max(0, i - 6), i)) if rng.random() > 0.08 else -1 for i in range(1, n)]
+    robot = random_tree(parents, seed=1000 + n, prismatic_every=prismatic_every, name=f"nobody_compiled_n{n}")
+    rbd = RBDReference(robot, build=False, generic="only"); om = orc.model_from_robot(robot)
+    B = 70
+    q = rng.uniform(-np.pi, np.pi, (B, n)); qd = rng.uniform(-1, 1, (B, n)); qdd = rng.uniform(-1, 1, (B, n))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    c_ref, dc_ref = orc.rnea_grad(om, q, qd, qdd, return_c=True)
+    c, dc = rbd.rnea_grad(tq, tqd, tqdd, return_c=True)
+    check("dc_du", dc, dc_ref, TOL64); check("c", c, c_ref, TOL64)
+    _, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    _, vr, ar, fr = orc.rnea(om, q, qd, qdd)
+    check("v", v, vr, TOL64); check("a", a, ar, TOL64); check("f", f, fr, TOL64)
+    Mi_ref = orc.minv(om, q)
+    check("Minv", rbd.minv(tq), Mi_ref, 1e-9)
+    sq, sqd, sqdd = dev_tensors(torch.float32, q, qd, qdd)
+    check("dc_du f32", rbd.rnea_grad(sq, sqd, sqdd), dc_ref, TOL32)
+    check("c f32", rbd.rnea(sq, sqd, sqdd, outputs="c")[0], c_ref, TOL32)
+
+
 def test_generic_equals_the_specialised_library_to_rounding_at_full_size():
     """configs[3]'s shape through both libraries (B = 131 072 rows of the 7-DoF arm, fp32): the model-handle kernels
     and the robot's own kernels agree row by row to the fp32 tolerance (they are different evaluation orders of the
