@@ -10,11 +10,12 @@
  * What it computes.  The reference's own recursions, literally, on dense 6x6 operands in body coordinates:
  *   rbd_g_rnea       /root/reference/RBDReference.py:559-628   (rnea_fpass, rnea_bpass, rnea)
  *   rbd_g_rnea_grad  :1127-1368  (rnea_grad_fpass_dq/dqd, rnea_grad_bpass_dq/dqd incl. the literal fxS term, rnea_grad)
- *   rbd_g_minv       :630-806    (minv_bpass, minv_fpass, minv; fixed-base branches)
+ *   rbd_g_minv       :630-806    (minv_bpass, minv_fpass, minv; fixed- and floating-base branches)
  *   rbd_g_forward_dynamics(_grad)  :1371-1384
  * Joints: X_i(q) = X0_i + Xs_i f1(q) + Xc_i f2(q) with (f1, f2) = (sin q, cos q) for joint_type 0 (revolute, any
  * axis) and (q, 0) for joint_type 1 (prismatic) -- SURVEY.md Appendix A: three samples of the robot's Xmat closure
- * recover the three matrices exactly; S_i is any 6-vector.  Fixed base, 1-DoF joints, n <= RBD_G_MAX_BODIES.
+ * recover the three matrices exactly; S_i is any 6-vector.  1-DoF joints, n <= RBD_G_MAX_BODIES, fixed base or ONE
+ * floating base at body 0 (rbd_model_desc.floating_base; rbd_g_rnea_grad then needs n >= 6, as the reference does).
  * One configuration per lane, per-lane state in private memory: correct and general, several times slower than the
  * specialised kernels (DESIGN.md §3.8 has the measured ratio) -- a first-use path, not the headline path.
  *
@@ -54,6 +55,11 @@ typedef struct rbd_model_desc {
   const double* Xc;           /* [n,36] (ignored for joint_type 1)                                        */
   const double* I;            /* [n,36] spatial inertia (get_Imat_by_id)                                  */
   const double* damping;      /* [n]   (get_damping_by_id)                                                */
+  int32_t floating_base;      /* 1: body 0 is attached by the 6-DoF base joint (S = eye(6), q[0:6] = px py pz rx ry rz,
+                                 X_0 = plux(Rz Ry Rx, p); RBDReference.py:585-593, :634-637, :652-691): its entries of
+                                 joint_type / S / X0 / Xs / Xc are not read, every other body must descend from it, and
+                                 q, qd, qdd, c, u have nv = n + 5 columns (body i >= 1 owns index i + 5), dc_du is
+                                 [B, nv, 2 nv], Minv [B, nv, nv]; v, a, f stay [B, 6, n]                               */
 } rbd_model_desc;
 
 int rbd_g_abi_version(void);
@@ -62,7 +68,8 @@ const char* rbd_g_last_error(void);
 /* Validates the description, uploads an fp32 and an fp64 copy to `device`, returns the handle in *out. */
 int rbd_model_create(const rbd_model_desc* desc, int device, rbd_model** out);
 void rbd_model_destroy(rbd_model* m);
-int rbd_model_n(const rbd_model* m);
+int rbd_model_n(const rbd_model* m);   /* bodies */
+int rbd_model_nv(const rbd_model* m);  /* velocities: n, or n + 5 with a floating base */
 
 /* Replaces RBDReference.rnea (RBDReference.py:623): c [B,n]; v, a, f [B,6,n] (nullable, f accumulated);
  * qdd NULL = the reference's qdd=None. */

@@ -128,7 +128,7 @@ class RbdLibrary:
 
     ``generic`` ('auto' | 'only' | 'never'; default from ``RBD_GENERIC``, else 'auto'): the MODEL-HANDLE library
     (include/rbd_generic.h, ``generic.GenericModel``) serves rnea / rnea_grad / minv / forward_dynamics(_grad) of a
-    fixed-base robot with no per-robot compilation at all.  'auto': it answers while the robot's own library is being
+    fixed- or floating-base robot with no per-robot compilation at all.  'auto': it answers while the robot's own library is being
     built in the background (first call after ``RBDReference(robot)`` returns in milliseconds instead of after a
     family build) and keeps answering if that build cannot happen (no hipcc on the machine); the other entry points
     still wait for their family library.  'only': nothing is built or loaded per robot.  'never': as before.
@@ -153,13 +153,13 @@ class RbdLibrary:
             generic = {"0": "never", "1": "auto", "": "auto"}.get(os.environ.get("RBD_GENERIC", "auto"), os.environ.get("RBD_GENERIC", "auto"))
         if generic not in ("auto", "only", "never"):
             raise ValueError("generic must be 'auto', 'only' or 'never'")
-        self._generic_mode = "never" if model.floating else generic
+        self._generic_mode = generic
         self._generic = None
         if self._generic_mode == "only":
             from .generic import GenericModel
             self._generic = GenericModel(model, build=build)       # raises if the library is missing and cannot be built
             return
-        if build and lazy and not model.floating and not full_library_ready(model):
+        if build and lazy and (not model.floating or generic != "never") and not full_library_ready(model):
             def work():
                 try:
                     build_model(model)

@@ -28,7 +28,8 @@ constexpr int MB = RBD_G_MAX_BODIES;
 
 template <class T>
 struct DevModel {
-  int n;
+  int n;                        // bodies
+  int fb;                       // 1: body 0 is the floating base (6-DoF joint, S = eye(6), q[0:6] = px py pz rx ry rz)
   int parent[MB];
   int jtype[MB];
   unsigned long long anc[MB];   // bit j of anc[i]: j == i or j is an ancestor of i
@@ -120,27 +121,78 @@ GDEV T dot6g(const T* a, const T* b) {
   return acc;
 }
 
+// world -> base transform of the 6-DoF base joint: plux(Rz(rz) Ry(ry) Rx(rx), p) with the coordinate-transform
+// rotations (robot.floating_base_X; RBDReference.py:634-637).  bt = {sx, cx, sy, cy, sz, cz, px, py, pz}
+template <class T>
+GDEV void base_X(const T (&bt)[9], T (&X)[36]) {
+  const T sx = bt[0], cx = bt[1], sy = bt[2], cy = bt[3], sz = bt[4], cz = bt[5];
+  // E = Rz Ry Rx,  Rx = [[1,0,0],[0,c,s],[0,-s,c]], Ry = [[c,0,-s],[0,1,0],[s,0,c]], Rz = [[c,s,0],[-s,c,0],[0,0,1]]
+  const T A[3][3] = {{cy, sy * sx, -sy * cx}, {T(0), cx, sx}, {sy, -cy * sx, cy * cx}};   // Ry Rx
+  T E[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    E[0][c] = fma(cz, A[0][c], sz * A[1][c]);
+    E[1][c] = fma(-sz, A[0][c], cz * A[1][c]);
+    E[2][c] = A[2][c];
+  }
+  const T p[3] = {bt[6], bt[7], bt[8]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // -E p^x : row r = -(E[r] x p)^T ... (E p^x)[r][c] = sum_k E[r][k] (p^x)[k][c];  p^x = [[0,-p2,p1],[p2,0,-p0],[-p1,p0,0]]
+    const T b0 = -(E[r][1] * p[2] - E[r][2] * p[1]);
+    const T b1 = -(E[r][2] * p[0] - E[r][0] * p[2]);
+    const T b2 = -(E[r][0] * p[1] - E[r][1] * p[0]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      X[r * 6 + c] = E[r][c];
+      X[r * 6 + 3 + c] = T(0);
+      X[(3 + r) * 6 + 3 + c] = E[r][c];
+    }
+    X[(3 + r) * 6 + 0] = b0; X[(3 + r) * 6 + 1] = b1; X[(3 + r) * 6 + 2] = b2;
+  }
+}
+
 template <class T, int NMAX>
 struct RneaState {
   T v[NMAX][6], a[NMAX][6], f[NMAX][6];
   T f1[NMAX], f2[NMAX], qd[NMAX];
+  T bt[9], qd6[6];              // floating base: trig / position of q[0:6], the base twist qd[0:6]
 };
+// X_i(q) of body i from the state (floating base: body 0 from bt)
+template <bool FB, class T, int NMAX>
+GDEV void body_X(const DevModel<T>* __restrict__ m, int i, const RneaState<T, NMAX>& st, T (&X)[36]) {
+  if (FB && i == 0) base_X(st.bt, X);
+  else build_X(m, i, st.f1[i], st.f2[i], X);
+}
 
 // rnea_fpass + rnea_bpass of one configuration (:559-621); leaves v, a, the ACCUMULATED f, (f1, f2), qd in st.
-// vo / ao / fo / co: this configuration's output rows (nullable); v, a, f are [6][n].
-template <class T, int NMAX>
+// vo / ao / fo / co: this configuration's output rows (nullable); v, a, f are [6][nb], c has nv entries.
+// FB: body 0 is the floating base -- X_0 from q[0:6], vJ = qd[0:6] (S = eye(6), :585), qdd[0:6] (:591), c[0:6] = f_0
+// (:612), body i >= 1 owns index i + 5.
+template <bool FB, class T, int NMAX>
 GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, const T* qd, const T* qdd, T grav,
                       RneaState<T, NMAX>& st, T* co, T* vo, T* ao, T* fo) {
+  constexpr int OFF = FB ? 5 : 0;
   for (int i = 0; i < n; ++i) {
-    T f1, f2;
-    joint_fun(m->jtype[i], q[i], f1, f2);
-    st.f1[i] = f1; st.f2[i] = f2;
-    const T qdi = qd[i];
-    st.qd[i] = qdi;
-    T X[36];
-    build_X(m, i, f1, f2, X);
+    T X[36], v[6], a[6], vJ[6], t[6];
     const int p = m->parent[i];
-    T v[6], a[6];
+    if (FB && i == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { sincos_g(q[3 + k], &st.bt[2 * k], &st.bt[2 * k + 1]); st.bt[6 + k] = q[k]; }
+      base_X(st.bt, X);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { vJ[r] = qd[r]; st.qd6[r] = vJ[r]; }
+      st.f1[0] = T(0); st.f2[0] = T(1); st.qd[0] = T(0);
+    } else {
+      T f1, f2;
+      joint_fun(m->jtype[i], q[i + OFF], f1, f2);
+      st.f1[i] = f1; st.f2[i] = f2;
+      const T qdi = qd[i + OFF];
+      st.qd[i] = qdi;
+      build_X(m, i, f1, f2, X);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) vJ[r] = m->S[i][r] * qdi;                                // :586
+    }
     if (p < 0) {                                            // v_p = 0, a_p = [0,0,0,0,0,-GRAVITY]  (:565-566, :576-581)
 #pragma unroll
       for (int r = 0; r < 6; ++r) { v[r] = T(0); a[r] = X[r * 6 + 5] * (-grav); }
@@ -148,16 +200,20 @@ GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, cons
       mv(X, st.v[p], v);
       mv(X, st.a[p], a);
     }
-    T S[6], vJ[6], t[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) { S[r] = m->S[i][r]; vJ[r] = S[r] * qdi; v[r] += vJ[r]; }   // :586-587
+    for (int r = 0; r < 6; ++r) v[r] += vJ[r];                                               // :587
     crm_mul(v, vJ, t);                                                                      // :588
 #pragma unroll
     for (int r = 0; r < 6; ++r) a[r] += t[r];
-    if (qdd != nullptr) {
-      const T qddi = qdd[i];
+    if (qdd != nullptr) {                                                                   // :589-593
+      if (FB && i == 0) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) a[r] = fma(S[r], qddi, a[r]);                             // :589-593
+        for (int r = 0; r < 6; ++r) a[r] += qdd[r];
+      } else {
+        const T qddi = qdd[i + OFF];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[r] = fma(m->S[i][r], qddi, a[r]);
+      }
     }
     T Iv[6], Ia[6], w[6];
     mvI(m, i, v, Iv);
@@ -174,7 +230,14 @@ GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, cons
     T f[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) f[r] = st.f[i][r];
-    if (co) co[i] = dot6g(m->S[i], f);                                                      // :612
+    if (co) {                                                                               // :612
+      if (FB && i == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) co[r] = f[r];
+      } else {
+        co[i + OFF] = dot6g(m->S[i], f);
+      }
+    }
     if (fo) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) fo[r * n + i] = f[r];
@@ -190,17 +253,17 @@ GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, cons
   }
 }
 
-template <class T, int NMAX>
+template <class T, int NMAX, bool FB>
 __global__ void __launch_bounds__(64) g_rnea_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
                                                     const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
                                                     long long B, T* __restrict__ c, T* __restrict__ v,
                                                     T* __restrict__ a, T* __restrict__ f) {
   const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  const int n = m->n;
+  const int n = m->n, nv = n + (FB ? 5 : 0);
   RneaState<T, NMAX> st;
-  rnea_config<T, NMAX>(m, n, q + b * n, qd + b * n, qdd ? qdd + b * n : nullptr, grav, st, c + b * n,
-                       v ? v + b * 6 * n : nullptr, a ? a + b * 6 * n : nullptr, f ? f + b * 6 * n : nullptr);
+  rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st, c + b * nv,
+                           v ? v + b * 6 * n : nullptr, a ? a + b * 6 * n : nullptr, f ? f + b * 6 * n : nullptr);
 }
 
 // df = I da + crf(dv)(I v) + crf(v)(I dv)   (:1179-1185, :1247-1252)
@@ -216,62 +279,86 @@ GDEV void df_of(const DevModel<T>* __restrict__ m, int i, const T* v, const T (&
   for (int r = 0; r < 6; ++r) out[r] = Ida[r] + w1[r] + w2[r];
 }
 
-template <class T, int NMAX>
+// Velocity damping exactly as the reference adds it (:1336-1341): matrix index = BODY id `ind`; for a floating base
+// the base contributes a whole 5 x 5 block and body ind >= 1 lands on row / column `ind` (not ind + 5).
+template <bool FB, class T>
+GDEV T damping_at(const DevModel<T>* __restrict__ m, int n, int row, int col) {
+  if (!FB) return row == col ? m->damping[row] : T(0);
+  T d = T(0);
+  if (row < 5 && col < 5) d += m->damping[0];
+  if (row == col && row >= 1 && row < n) d += m->damping[row];
+  return d;
+}
+
+template <class T, int NMAX, bool FB>
 __global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
                                                          const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
                                                          int use_damping, long long B, T* __restrict__ c,
                                                          T* __restrict__ dc) {
   const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  const int n = m->n;
+  constexpr int OFF = FB ? 5 : 0;
+  const int n = m->n, nv = n + OFF;
   RneaState<T, NMAX> st;
-  rnea_config<T, NMAX>(m, n, q + b * n, qd + b * n, qdd ? qdd + b * n : nullptr, grav, st, c ? c + b * n : nullptr,
-                       (T*)nullptr, (T*)nullptr, (T*)nullptr);                               // :1353
+  rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st, c ? c + b * nv : nullptr,
+                           (T*)nullptr, (T*)nullptr, (T*)nullptr);                           // :1353
   T dvq[NMAX][6], daq[NMAX][6], dfq[NMAX][6], dvd[NMAX][6], dad[NMAX][6], dfd[NMAX][6];
-  T* row = dc + b * 2 * n * n;
-  for (int c0 = 0; c0 < n; ++c0) {
-    // ---- forward recursions of column c0 over subtree(c0) ----
+  T* row = dc + b * 2 * nv * nv;
+  for (int col = 0; col < nv; ++col) {
+    const int c0 = FB ? (col < 6 ? 0 : col - 5) : col;      // the body that owns the column
+    // ---- forward recursions of the column over subtree(c0) ----
     for (int i = c0; i < n; ++i) {
       if (!((m->anc[i] >> c0) & 1ull)) continue;
       T X[36], S[6];
-      build_X(m, i, st.f1[i], st.f2[i], X);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+      body_X<FB>(m, i, st, X);
       const int p = m->parent[i];
-      const T qdi = st.qd[i];
       T vq[6], aq[6], vd[6], ad[6], t[6];
-      if (i == c0) {
-        T xa[6];
-        if (p >= 0) {
-          T xv[6];
-          mv(X, st.v[p], xv);
-          crm_mul(xv, S, vq);                               // dv[:,i,i] += crm(X v_p) S     (:1157-1159)
-          mv(X, st.a[p], xa);
-        } else {
+      if (FB && i == 0) {                                   // base column `col` (S = e_col); :1175, :1231, :1236-1243
+        T xa[6], e[6];
 #pragma unroll
-          for (int r = 0; r < 6; ++r) { vq[r] = T(0); xa[r] = X[r * 6 + 5] * (-grav); }
-        }
-        crm_mul(vq, S, t);                                  // da[:,c,i] += qd_i crm(dv[:,c,i]) S   (:1164-1170)
-        crm_mul(xa, S, aq);                                 // da[:,i,i] += crm(X a_p) S            (:1172-1175)
+        for (int r = 0; r < 6; ++r) { xa[r] = X[r * 6 + 5] * (-grav); e[r] = r == col ? T(1) : T(0); vq[r] = T(0); vd[r] = e[r]; }
+        crm_mul(xa, e, aq);                                 // da[:, col, 0] = crm(X a_grav) S
+        crm_mul(vd, st.qd6, t);                             // sum_ii qd_ii crm(dv) S[ii]
+        crm_mul(st.v[0], e, ad);                            // + crm(v) S
 #pragma unroll
-        for (int r = 0; r < 6; ++r) aq[r] = fma(qdi, t[r], aq[r]);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) vd[r] = S[r];           // dv[:,i,i] += S                       (:1231)
-        crm_mul(vd, S, t);                                  // (:1235-1240)
-        crm_mul(st.v[i], S, ad);                            // da[:,i,i] += crm(v_i) S              (:1243)
-#pragma unroll
-        for (int r = 0; r < 6; ++r) ad[r] = fma(qdi, t[r], ad[r]);
+        for (int r = 0; r < 6; ++r) ad[r] += t[r];
       } else {
-        mv(X, dvq[p], vq);                                  // (:1157, :1162-1163)
-        mv(X, daq[p], aq);
-        crm_mul(vq, S, t);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) aq[r] = fma(qdi, t[r], aq[r]);
-        mv(X, dvd[p], vd);                                  // (:1229-1234)
-        mv(X, dad[p], ad);
-        crm_mul(vd, S, t);
+        for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+        const T qdi = st.qd[i];
+        if (i == c0) {
+          T xa[6];
+          if (p >= 0) {
+            T xv[6];
+            mv(X, st.v[p], xv);
+            crm_mul(xv, S, vq);                             // dv[:,i,i] += crm(X v_p) S     (:1157-1159)
+            mv(X, st.a[p], xa);
+          } else {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) ad[r] = fma(qdi, t[r], ad[r]);
+            for (int r = 0; r < 6; ++r) { vq[r] = T(0); xa[r] = X[r * 6 + 5] * (-grav); }
+          }
+          crm_mul(vq, S, t);                                // da[:,c,i] += qd_i crm(dv[:,c,i]) S   (:1164-1170)
+          crm_mul(xa, S, aq);                               // da[:,i,i] += crm(X a_p) S            (:1172-1175)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) aq[r] = fma(qdi, t[r], aq[r]);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) vd[r] = S[r];         // dv[:,i,i] += S                       (:1231)
+          crm_mul(vd, S, t);                                // (:1235-1240)
+          crm_mul(st.v[i], S, ad);                          // da[:,i,i] += crm(v_i) S              (:1243)
+#pragma unroll
+          for (int r = 0; r < 6; ++r) ad[r] = fma(qdi, t[r], ad[r]);
+        } else {
+          mv(X, dvq[p], vq);                                // (:1157, :1162-1163)
+          mv(X, daq[p], aq);
+          crm_mul(vq, S, t);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) aq[r] = fma(qdi, t[r], aq[r]);
+          mv(X, dvd[p], vd);                                // (:1229-1234)
+          mv(X, dad[p], ad);
+          crm_mul(vd, S, t);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) ad[r] = fma(qdi, t[r], ad[r]);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) { dvq[i][r] = vq[r]; daq[i][r] = aq[r]; dvd[i][r] = vd[r]; dad[i][r] = ad[r]; }
@@ -284,22 +371,29 @@ __global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __re
 #pragma unroll
       for (int r = 0; r < 6; ++r) { dfq[x][r] = T(0); dfd[x][r] = T(0); }
     }
-    // ---- backward sweep of column c0 over subtree(c0) and the ancestors of c0 ----
+    // ---- backward sweep of the column over subtree(c0) and the ancestors of c0 ----
     for (int i = n - 1; i >= 0; --i) {
       const bool rel = (((m->anc[i] >> c0) & 1ull) != 0) || (((m->anc[c0] >> i) & 1ull) != 0);
+      T gq[6], gd[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { gq[r] = rel ? dfq[i][r] : T(0); gd[r] = rel ? dfd[i][r] : T(0); }
+      if (FB && i == 0) {                                   // dc[0:6, :] = df[:, :, 0]   (:1282, :1325 with S = eye(6))
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          row[r * 2 * nv + col] = gq[r];
+          row[r * 2 * nv + nv + col] = gd[r] + (use_damping ? damping_at<FB>(m, n, r, col) : T(0));
+        }
+        continue;
+      }
       T eq = T(0), ed = T(0);
       if (rel) {
-        T gq[6], gd[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { gq[r] = dfq[i][r]; gd[r] = dfd[i][r]; }
         eq = dot6g(m->S[i], gq);                            // dc_dq[i,:] = S^T df[:,:,i]   (:1284)
         ed = dot6g(m->S[i], gd);                            // (:1325)
-        if (i == c0 && use_damping) ed += m->damping[i];    // (:1336-1341)
         const int p = m->parent[i];
         if (p >= 0) {
           T X[36], t[6];
           build_X(m, i, st.f1[i], st.f2[i], X);
-          if (i == c0) {                                    // df[:,i,p] += X^T fxS(S, f_i), fxS = -crm(f_i) S  (:1292-1294)
+          if (i == c0 && (!FB || col >= 6)) {               // df[:,i,p] += X^T fxS(S, f_i), fxS = -crm(f_i) S  (:1292-1294)
             T g[6];
             crm_mul(st.f[i], m->S[i], g);
 #pragma unroll
@@ -313,27 +407,48 @@ __global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __re
           for (int r = 0; r < 6; ++r) dfd[p][r] += t[r];
         }
       }
-      row[i * 2 * n + c0] = eq;
-      row[i * 2 * n + n + c0] = ed;
+      if (use_damping) ed += damping_at<FB>(m, n, i + OFF, col);   // (:1336-1341)
+      row[(i + OFF) * 2 * nv + col] = eq;
+      row[(i + OFF) * 2 * nv + nv + col] = ed;
     }
   }
 }
 
-template <class T, int NMAX>
+// in-place inverse of a symmetric positive definite 6 x 6 (Gauss-Jordan, no pivoting needed)
+template <class T>
+GDEV void inv6_spd(T (&A)[36]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const T d = T(1) / A[k * 6 + k];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) A[k * 6 + c] = (c == k) ? d : A[k * 6 + c] * d;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (r == k) continue;
+      const T f = A[r * 6 + k];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) A[r * 6 + c] = (c == k) ? -(f * d) : fma(-f, A[k * 6 + c], A[r * 6 + c]);
+    }
+  }
+}
+
+template <class T, int NMAX, bool FB>
 __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, long long B,
                                                     int dense, T* __restrict__ Minv) {
   const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  const int n = m->n;
+  constexpr int OFF = FB ? 5 : 0;
+  const int n = m->n, nv = n + OFF;
   T IA[NMAX][36];
   T U[NMAX][6], Di[NMAX], f1[NMAX], f2[NMAX];
   for (int i = 0; i < n; ++i) {
-    joint_fun(m->jtype[i], q[b * n + i], f1[i], f2[i]);
+    if (FB && i == 0) { f1[0] = T(0); f2[0] = T(1); }
+    else joint_fun(m->jtype[i], q[b * nv + i + OFF], f1[i], f2[i]);
 #pragma unroll
     for (int k = 0; k < 36; ++k) IA[i][k] = m->I[i][k];      // IA = deepcopy(I)   (:662)
   }
-  // articulated inertias (:697-700, :728-733)
-  for (int i = n - 1; i >= 0; --i) {
+  // articulated inertias (:697-700, :728-733); the floating base itself has no parent: IA_0 is inverted below
+  for (int i = n - 1; i >= (FB ? 1 : 0); --i) {
     T A[36], u[6], S[6];
 #pragma unroll
     for (int k = 0; k < 36; ++k) A[k] = IA[i][k];
@@ -374,11 +489,23 @@ __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restric
         }
     }
   }
+  T* out = Minv + b * nv * nv;
+  T fbi[36];                                                 // floating base: inv(S^T IA_0 S) = inv(IA_0)   (:679-683)
+  if (FB) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) fbi[k] = IA[0][k];
+    inv6_spd(fbi);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)                          // Minv[0:6, 0:6] = fb  (:685); the stored block is exactly symmetric
+        out[r * nv + cc] = cc >= r ? fbi[r * 6 + cc] : (dense ? fbi[cc * 6 + r] : T(0));
+  }
   T Mc[NMAX], F[NMAX][6];
-  T* out = Minv + b * n * n;
-  for (int c0 = 0; c0 < n; ++c0) {
+  for (int c0 = FB ? 1 : 0; c0 < n; ++c0) {                  // the column of body c0 (matrix index c0 + OFF)
     for (int i = 0; i <= c0; ++i) Mc[i] = T(0);
-    {                                                        // backward sweep of column c0: its root path (:700-726)
+    T F0[6];                                                 // floating base: the base rows of the column
+    {                                                        // backward sweep of the column: its root path (:700-726)
       T Fv[6];
       const T m0 = Di[c0];
       Mc[c0] = m0;
@@ -388,13 +515,31 @@ __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restric
         T X[36], Fp[6];
         build_X(m, i, f1[i], f2[i], X);
         mtv(X, Fv, Fp);
-        const T mp = -(Di[p] * dot6g(m->S[p], Fp));
-        Mc[p] = mp;
+        if (FB && p == 0) {                                  // Minv[0:6, sub] -= fb F[base slot][:, sub]   (:686-691)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) Fv[r] = fma(U[p][r], mp, Fp[r]);
+          for (int r = 0; r < 6; ++r) {
+            T acc = fbi[r * 6] * Fp[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) acc = fma(fbi[r * 6 + k], Fp[k], acc);
+            F0[r] = -acc;
+          }
+        } else {
+          const T mp = -(Di[p] * dot6g(m->S[p], Fp));
+          Mc[p] = mp;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) Fv[r] = fma(U[p][r], mp, Fp[r]);
+        }
       }
     }
-    for (int i = 0; i <= c0; ++i) {                          // forward sweep, rows <= c0 (:771-781)
+    if (FB) {                                                // F[0] = S Minv[0:6, :]   (:779)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        F[0][r] = F0[r];
+        out[r * nv + c0 + OFF] = F0[r];
+        out[(c0 + OFF) * nv + r] = dense ? F0[r] : T(0);
+      }
+    }
+    for (int i = FB ? 1 : 0; i <= c0; ++i) {                 // forward sweep, rows <= c0 (:771-781)
       const int p = m->parent[i];
       T mm = Mc[i];
       if (p >= 0) {
@@ -410,8 +555,8 @@ __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restric
 #pragma unroll
         for (int r = 0; r < 6; ++r) F[i][r] = m->S[i][r] * mm;
       }
-      out[i * n + c0] = mm;
-      if (i != c0) out[c0 * n + i] = dense ? mm : T(0);      // (:799-804)
+      out[(i + OFF) * nv + c0 + OFF] = mm;
+      if (i != c0) out[(c0 + OFF) * nv + i + OFF] = dense ? mm : T(0);      // (:799-804)
     }
   }
 }
@@ -467,7 +612,9 @@ int hip_fail(hipError_t e, const char* what) {
 
 struct rbd_model {
   int device;
-  int n;
+  int n;        // bodies
+  int fb;       // floating base
+  int nv;       // velocities: n, or n + 5 with a floating base
   rbdg::DevModel<float>* d32;
   rbdg::DevModel<double>* d64;
 };
@@ -485,15 +632,17 @@ template <class T>
 void fill(DevModel<T>& d, const rbd_model_desc* s) {
   std::memset(&d, 0, sizeof(d));
   d.n = s->n;
+  d.fb = s->floating_base ? 1 : 0;
   for (int i = 0; i < s->n; ++i) {
+    const bool base = d.fb && i == 0;                 // its joint is the 6-DoF base joint: S, X0, Xs, Xc are not read
     d.parent[i] = s->parent[i];
-    d.jtype[i] = s->joint_type[i];
+    d.jtype[i] = base ? 0 : s->joint_type[i];
     d.anc[i] = (1ull << i) | (s->parent[i] >= 0 ? d.anc[s->parent[i]] : 0ull);
-    for (int r = 0; r < 6; ++r) d.S[i][r] = (T)s->S[i * 6 + r];
+    for (int r = 0; r < 6; ++r) d.S[i][r] = base ? T(0) : (T)s->S[i * 6 + r];
     for (int k = 0; k < 36; ++k) {
-      d.X0[i][k] = (T)s->X0[i * 36 + k];
-      d.Xs[i][k] = (T)s->Xs[i * 36 + k];
-      d.Xc[i][k] = s->joint_type[i] == 0 ? (T)s->Xc[i * 36 + k] : T(0);
+      d.X0[i][k] = base ? T(k % 7 == 0 ? 1 : 0) : (T)s->X0[i * 36 + k];
+      d.Xs[i][k] = base ? T(0) : (T)s->Xs[i * 36 + k];
+      d.Xc[i][k] = (!base && s->joint_type[i] == 0) ? (T)s->Xc[i * 36 + k] : T(0);
       d.I[i][k] = (T)s->I[i * 36 + k];
     }
     d.damping[i] = (T)s->damping[i];
@@ -511,12 +660,20 @@ int check_call(const rbd_model* m, long long B, const char* who) {
   return 0;
 }
 
-#define RBDG_DISPATCH(n, CALL)             \
-  do {                                     \
-    if ((n) <= 8) { CALL(8); }             \
-    else if ((n) <= 16) { CALL(16); }      \
-    else if ((n) <= 32) { CALL(32); }      \
-    else { CALL(64); }                     \
+#define RBDG_DISPATCH(m, CALL)                                        \
+  do {                                                               \
+    const int n_ = (m)->n;                                           \
+    if ((m)->fb) {                                                   \
+      if (n_ <= 8) { CALL(8, true); }                                \
+      else if (n_ <= 16) { CALL(16, true); }                         \
+      else if (n_ <= 32) { CALL(32, true); }                         \
+      else { CALL(64, true); }                                       \
+    } else {                                                         \
+      if (n_ <= 8) { CALL(8, false); }                               \
+      else if (n_ <= 16) { CALL(16, false); }                        \
+      else if (n_ <= 32) { CALL(32, false); }                        \
+      else { CALL(64, false); }                                      \
+    }                                                                \
   } while (0)
 
 template <class T>
@@ -525,8 +682,8 @@ int rnea_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav,
   if (!q || !qd || !c) return fail(RBD_G_ERR_ARG, "rbd_g_rnea: q, qd, c must not be null");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM) hipLaunchKernelGGL((g_rnea_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f)
-  RBDG_DISPATCH(m->n, CALL);
+#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f)
+  RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea launch");
@@ -535,10 +692,12 @@ template <class T>
 int grad_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav, int damp, long long B, T* c, T* dc, void* stream) {
   if (int rc = check_call(m, B, "rbd_g_rnea_grad")) return rc;
   if (!q || !qd || !dc) return fail(RBD_G_ERR_ARG, "rbd_g_rnea_grad: q, qd, dc_du must not be null");
+  if (m->fb && m->n < 6)      // the reference's own pass indexes bodies 0..5 for the base and raises IndexError (:1168)
+    return fail(RBD_G_ERR_UNSUPPORTED, "rbd_g_rnea_grad: a floating-base robot needs >= 6 bodies (RBDReference.py:1168 raises for fewer)");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
-  RBDG_DISPATCH(m->n, CALL);
+#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
+  RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea_grad launch");
@@ -549,8 +708,8 @@ int minv_host(const rbd_model* m, const T* q, long long B, int dense, T* Minv, v
   if (!q || !Minv) return fail(RBD_G_ERR_ARG, "rbd_g_minv: q, Minv must not be null");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM) hipLaunchKernelGGL((g_minv_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv)
-  RBDG_DISPATCH(m->n, CALL);
+#define CALL(NM, FB) hipLaunchKernelGGL((g_minv_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv)
+  RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_minv launch");
@@ -570,7 +729,7 @@ int fd_host(const rbd_model* m, const T* q, const T* qd, const T* u, T grav, lon
   if (int rc = check_call(m, B, who)) return rc;
   if (!q || !qd || !u || !qdd || (grad && !dout)) return fail(RBD_G_ERR_ARG, "%s: null argument", who);
   if (B == 0) return 0;
-  const int n = m->n;
+  const int n = m->nv;
   const size_t need = fd_ws(n, B, (int)sizeof(T), grad ? 1 : 0);
   if (!ws || wsb < need) return fail(RBD_G_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, wsb);
   char* w = (char*)ws;
@@ -613,6 +772,13 @@ int rbd_model_create(const rbd_model_desc* s, int device, rbd_model** out) {
     return fail(RBD_G_ERR_ARG, "rbd_model_create: null array in the description");
   for (int i = 0; i < s->n; ++i) {
     if (s->parent[i] < -1 || s->parent[i] >= i) return fail(RBD_G_ERR_ARG, "rbd_model_create: parent[%d] = %d must be -1 or precede the body", i, s->parent[i]);
+    if (s->floating_base && i > 0 && s->parent[i] < 0) return fail(RBD_G_ERR_ARG, "rbd_model_create: floating base: body %d must descend from body 0", i);
+    if (s->floating_base && i == 0) {
+      bool ok0 = std::isfinite(s->damping[0]);
+      for (int k = 0; k < 36; ++k) ok0 = ok0 && std::isfinite(s->I[k]);
+      if (!ok0) return fail(RBD_G_ERR_ARG, "rbd_model_create: body 0 has a non-finite constant");
+      continue;
+    }
     if (s->joint_type[i] != 0 && s->joint_type[i] != 1) return fail(RBD_G_ERR_UNSUPPORTED, "rbd_model_create: joint_type[%d] = %d", i, s->joint_type[i]);
     bool ok = std::isfinite(s->damping[i]);
     for (int r = 0; r < 6; ++r) ok = ok && std::isfinite(s->S[i * 6 + r]);
@@ -625,7 +791,7 @@ int rbd_model_create(const rbd_model_desc* s, int device, rbd_model** out) {
   if (e != hipSuccess) return hip_fail(e, "rbd_model_create");
   e = hipSetDevice(device);
   if (e != hipSuccess) return hip_fail(e, "rbd_model_create: hipSetDevice");
-  rbd_model* m = new (std::nothrow) rbd_model{device, s->n, nullptr, nullptr};
+  rbd_model* m = new (std::nothrow) rbd_model{device, s->n, s->floating_base ? 1 : 0, s->n + (s->floating_base ? 5 : 0), nullptr, nullptr};
   DevModel<float>* h32 = new (std::nothrow) DevModel<float>;
   DevModel<double>* h64 = new (std::nothrow) DevModel<double>;
   int rc = 0;
@@ -661,6 +827,7 @@ void rbd_model_destroy(rbd_model* m) {
   delete m;
 }
 int rbd_model_n(const rbd_model* m) { return m ? m->n : 0; }
+int rbd_model_nv(const rbd_model* m) { return m ? m->nv : 0; }
 
 int rbd_g_rnea_f32(const rbd_model* m, const float* q, const float* qd, const float* qdd, float g, int64_t B, float* c, float* v, float* a, float* f, void* st) {
   return rbdg::rnea_host<float>(m, q, qd, qdd, g, B, c, v, a, f, st);
@@ -679,7 +846,7 @@ int rbd_g_minv_f64(const rbd_model* m, const double* q, int64_t B, int dense, do
 
 size_t rbd_g_fd_workspace_bytes(const rbd_model* m, int64_t B, int elem_size, int with_grad) {
   if (!m || (elem_size != 4 && elem_size != 8)) return 0;
-  return rbdg::fd_ws(m->n, B, elem_size, with_grad);
+  return rbdg::fd_ws(m->nv, B, elem_size, with_grad);
 }
 int rbd_g_forward_dynamics_f32(const rbd_model* m, const float* q, const float* qd, const float* u, float g, int64_t B, float* qdd, void* ws, size_t wsb, void* st) {
   return rbdg::fd_host<float>(m, q, qd, u, g, B, qdd, nullptr, false, ws, wsb, st);

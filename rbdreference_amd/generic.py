@@ -21,7 +21,7 @@ RBD_G_MAX_BODIES = 64
 
 # every symbol include/rbd_generic.h declares (tests check the built library exports all of them)
 GENERIC_EXPORTED_SYMBOLS = [
-    "rbd_g_abi_version", "rbd_g_last_error", "rbd_model_create", "rbd_model_destroy", "rbd_model_n",
+    "rbd_g_abi_version", "rbd_g_last_error", "rbd_model_create", "rbd_model_destroy", "rbd_model_n", "rbd_model_nv",
     "rbd_g_rnea_f32", "rbd_g_rnea_f64", "rbd_g_rnea_grad_f32", "rbd_g_rnea_grad_f64",
     "rbd_g_minv_f32", "rbd_g_minv_f64", "rbd_g_fd_workspace_bytes",
     "rbd_g_forward_dynamics_f32", "rbd_g_forward_dynamics_f64",
@@ -33,7 +33,8 @@ class RbdModelDesc(Structure):
     _fields_ = [("abi_version", c_int32), ("n", c_int32),
                 ("parent", POINTER(c_int32)), ("joint_type", POINTER(c_int32)),
                 ("S", POINTER(c_double)), ("X0", POINTER(c_double)), ("Xs", POINTER(c_double)),
-                ("Xc", POINTER(c_double)), ("I", POINTER(c_double)), ("damping", POINTER(c_double))]
+                ("Xc", POINTER(c_double)), ("I", POINTER(c_double)), ("damping", POINTER(c_double)),
+                ("floating_base", c_int32)]
 
 
 def _declare(lib):
@@ -47,6 +48,8 @@ def _declare(lib):
     lib.rbd_model_destroy.argtypes = [c_void_p]
     lib.rbd_model_n.restype = c_int
     lib.rbd_model_n.argtypes = [c_void_p]
+    lib.rbd_model_nv.restype = c_int
+    lib.rbd_model_nv.argtypes = [c_void_p]
     lib.rbd_g_fd_workspace_bytes.restype = c_size_t
     lib.rbd_g_fd_workspace_bytes.argtypes = [c_void_p, c_int64, c_int, c_int]
     for sfx, ft in (("f32", c_float), ("f64", c_double)):
@@ -92,13 +95,13 @@ def load_generic_library(build: bool = True):
 def model_desc_arrays(m: PackedModel):
     """Packed model -> the host arrays of ``rbd_model_desc``: ``X_i(q) = X_J(q) X_i(0)`` split into its constant, sine
     (or linear, for a prismatic joint) and cosine parts (exact: no sampling of transcendental functions)."""
-    if m.floating:
-        raise ValueError("the model-handle library serves fixed-base robots")
     n = m.n
     S = np.zeros((n, 6)); X0 = np.zeros((n, 6, 6)); Xs = np.zeros((n, 6, 6)); Xc = np.zeros((n, 6, 6))
     for i in range(n):
         k = m.axis[i]; a, b = (k + 1) % 3, (k + 2) % 3
         C0 = np.zeros((6, 6)); Cs = np.zeros((6, 6)); Cc = np.zeros((6, 6))
+        if m.floating and i == 0:
+            continue                     # the 6-DoF base joint: rbd_model_desc.floating_base, nothing of body 0's joint is read
         if m.jtype[i] == 0:
             S[i, k] = 1.0
             for o in (0, 3):
@@ -112,7 +115,8 @@ def model_desc_arrays(m: PackedModel):
         else:
             raise ValueError(f"body {i}: joint type {m.jtype[i]} is not served by the model-handle library")
         X0[i] = C0 @ m.Xtree[i]; Xs[i] = Cs @ m.Xtree[i]; Xc[i] = Cc @ m.Xtree[i]
-    return dict(parent=np.ascontiguousarray(m.parent, dtype=np.int32), joint_type=np.ascontiguousarray(m.jtype, dtype=np.int32),
+    jt = [0 if (m.floating and i == 0) else t for i, t in enumerate(m.jtype)]
+    return dict(parent=np.ascontiguousarray(m.parent, dtype=np.int32), joint_type=np.ascontiguousarray(jt, dtype=np.int32),
                 S=np.ascontiguousarray(S), X0=np.ascontiguousarray(X0), Xs=np.ascontiguousarray(Xs), Xc=np.ascontiguousarray(Xc),
                 I=np.ascontiguousarray(m.I, dtype=np.float64), damping=np.ascontiguousarray(m.damping, dtype=np.float64))
 
@@ -148,7 +152,8 @@ class GenericModel:
                     a = self._arr
                     d = RbdModelDesc(RBD_G_ABI_VERSION, self.model.n,
                                      a["parent"].ctypes.data_as(POINTER(c_int32)), a["joint_type"].ctypes.data_as(POINTER(c_int32)),
-                                     *[a[k].ctypes.data_as(POINTER(c_double)) for k in ("S", "X0", "Xs", "Xc", "I", "damping")])
+                                     *[a[k].ctypes.data_as(POINTER(c_double)) for k in ("S", "X0", "Xs", "Xc", "I", "damping")],
+                                     1 if self.model.floating else 0)
                     out = c_void_p()
                     rc = self.lib.rbd_model_create(ctypes.byref(d), dev, ctypes.byref(out))
                     if rc != 0:

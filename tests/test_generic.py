@@ -7,7 +7,7 @@ Same checkers as tests/test_gpu_parity.py -- the golden vectors generated from t
 import numpy as np
 import pytest
 
-from conftest import all_golden_names, load_golden, make_robot
+from conftest import all_golden_names, fb_golden_names, load_golden, make_robot, rel_err_rows
 from test_gpu_parity import TOL32, TOL64, _torch, check, check_conditioned, dev_tensors
 
 pytestmark = pytest.mark.gpu
@@ -122,6 +122,70 @@ def test_generic_serves_robots_nobody_compiled_for(n, prismatic_every):
     sq, sqd, sqdd = dev_tensors(torch.float32, q, qd, qdd)
     check("dc_du f32", rbd.rnea_grad(sq, sqd, sqdd), dc_ref, TOL32)
     check("c f32", rbd.rnea(sq, sqd, sqdd, outputs="c")[0], c_ref, TOL32)
+
+
+@pytest.mark.parametrize("name", fb_golden_names())
+def test_generic_floating_base_vs_golden(name, prec):
+    """Floating-base robots on the model-handle library (rbd_model_desc.floating_base) against the real reference's
+    outputs: rnea (:585-593), rnea_grad incl. the base's six twist columns and the literal damping block
+    (:1141-1341), minv with the 6 x 6 base block (:652-691, :779), forward_dynamics(_grad) (:1371-1384)."""
+    from rbdreference_amd._lib import RBD_ERR_UNSUPPORTED, RbdError
+    dt, tol = prec
+    torch = _torch()
+    g = load_golden(name); rbd = generic_for(name)
+    assert rbd.model.floating and rbd.nv == rbd.n + 5
+    q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    c, v, a, f = rbd.rnea(q, qd, qdd)
+    assert rbd._lib.served_by_generic()
+    check("c", c, g["c"], tol); check("v", v, g["fpass_v"], tol); check("a", a, g["fpass_a"], tol); check("f", f, g["f_acc"], tol)
+    check("c_noqdd", rbd.rnea(q, qd)[0], g["c_noqdd"], tol)
+    Mi = rbd.minv(q)
+    check("Minv_dense", Mi, g["Minv_dense"], tol)
+    assert torch.equal(Mi, Mi.transpose(1, 2))
+    check("Minv_upper", rbd.minv(q, output_dense=False), np.triu(g["Minv_upper"]), tol)
+    cond = np.array([np.linalg.cond(M) for M in g["Minv_dense"]])
+
+    def check_cond(nm, got, want, slack):
+        gn = got.double().cpu().numpy().reshape(len(cond), -1); w = np.asarray(want).reshape(len(cond), -1)
+        err = np.abs(gn - w).max(1) / np.abs(w).max(1)
+        assert np.all(err <= slack * 2.0 ** -24 * cond), (nm, err, cond)
+    if dt == torch.float32:
+        check_cond("fd_qdd", rbd.forward_dynamics(q, qd, qdd), g["fd_qdd"], 8.0)
+    else:
+        check("fd_qdd", rbd.forward_dynamics(q, qd, qdd), g["fd_qdd"], 1e-9)
+    if rbd.n < 6:      # the reference raises IndexError (:1168): refused here as well
+        with pytest.raises(RbdError) as ei:
+            rbd.rnea_grad(q, qd, qdd)
+        assert ei.value.code == RBD_ERR_UNSUPPORTED and ">= 6 bodies" in str(ei.value)
+        return
+    check("dc_du", rbd.rnea_grad(q, qd, qdd), g["dc_du"], tol)
+    check("dc_du_noqdd", rbd.rnea_grad(q, qd), g["dc_du_noqdd"], tol)
+    check("dc_du_damped", rbd.rnea_grad(q, qd, qdd, USE_VELOCITY_DAMPING=True), g["dc_du_damped"], tol)
+    c1, dc1 = rbd.rnea_grad(q, qd, qdd, return_c=True)
+    check("c of rnea_grad", c1, g["c"], tol)
+    a1, a2 = rbd.forward_dynamics_grad(q, qd, qdd)
+    if dt == torch.float64:
+        check("fd_dq", a1.contiguous(), g["fd_dq"], 1e-9); check("fd_dqd", a2.contiguous(), g["fd_dqd"], 1e-9)
+    else:
+        check_cond("fd_dq", a1, g["fd_dq"], 16.0); check_cond("fd_dqd", a2, g["fd_dqd"], 16.0)
+
+
+@pytest.mark.parametrize("B", [1, 65, 700])
+def test_generic_floating_base_ragged_batches_vs_oracle(B):
+    from oracle import rbd_oracle_fb as fbo
+    torch = _torch()
+    name = "fb_quadruped_like"
+    rbd = generic_for(name); m = fbo.model_from_robot(make_robot(name))
+    rng = np.random.default_rng(B)
+    q = rng.uniform(-np.pi, np.pi, (B, m.n)); qd = rng.uniform(-1, 1, (B, m.n)); qdd = rng.uniform(-1, 1, (B, m.n))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    c, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    cr, vr, ar, fr = fbo.rnea(m, q, qd, qdd)
+    for got, want in ((c, cr), (v, vr), (a, ar), (f, fr)):
+        assert rel_err_rows(got.cpu().numpy(), want) <= 1e-11
+    assert rel_err_rows(rbd.minv(tq).cpu().numpy(), fbo.minv(m, q)) <= 1e-11
+    assert rel_err_rows(rbd.rnea_grad(tq, tqd, tqdd).cpu().numpy(), fbo.rnea_grad(m, q, qd, qdd)) <= 1e-11
+    assert rel_err_rows(rbd.rnea_grad(tq.float(), tqd.float(), tqdd.float()).double().cpu().numpy(), fbo.rnea_grad(m, q, qd, qdd)) <= 1e-5
 
 
 def test_generic_equals_the_specialised_library_to_rounding_at_full_size():

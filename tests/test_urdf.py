@@ -191,11 +191,13 @@ def test_rejections():
 
 @pytest.mark.gpu
 def test_urdf_robot_runs_through_the_hip_path():
-    """A robot straight from URDF text: build-on-first-use, then parity with the oracle."""
+    """A robot straight from URDF text, first use end to end: the model-handle library answers rnea_grad / minv at
+    once while the robot's own library compiles in the background, `aba` (not served there) waits for its family
+    library, and after the hand-over the specialised kernels give the same numbers -- all against the oracle."""
     import torch
     from rbdreference_amd import RBDReference
     robot = loads_urdf(URDF)
-    rbd = RBDReference(robot)                      # compiles the library for this robot on first use
+    rbd = RBDReference(robot)                      # returns at once; compiles the library for this robot in the background
     om = orc.model_from_robot(robot)
     rng = np.random.default_rng(9)
     q, qd, qdd = rng.uniform(-3, 3, (50, 4)), rng.uniform(-1, 1, (50, 4)), rng.uniform(-1, 1, (50, 4))
@@ -206,3 +208,9 @@ def test_urdf_robot_runs_through_the_hip_path():
     assert np.abs(dc.cpu().numpy() - dc_ref).max() < 1e-10 * np.abs(dc_ref).max()
     assert np.abs(rbd.minv(tq).cpu().numpy() - orc.minv(om, q)).max() < 1e-9 * np.abs(orc.minv(om, q)).max()
     assert np.abs(rbd.aba(tq, tqd, tqdd).cpu().numpy() - orc.aba(om, q, qd, qdd)).max() < 1e-8 * np.abs(orc.aba(om, q, qd, qdd)).max()
+    rbd._lib.wait_specialized()                    # hand-over: from here on the robot's own kernels
+    c2, dc2 = rbd.rnea_grad(tq, tqd, tqdd, return_c=True)
+    assert not rbd._lib.served_by_generic() and rbd._lib.kernel_name(1, 8, 50).startswith("rnea_grad")
+    assert np.abs(dc2.cpu().numpy() - dc_ref).max() < 1e-10 * np.abs(dc_ref).max()
+    assert np.abs(c2.cpu().numpy() - c_ref).max() < 1e-10 * np.abs(c_ref).max()
+    assert np.abs(rbd.minv(tq).cpu().numpy() - orc.minv(om, q)).max() < 1e-9 * np.abs(orc.minv(om, q)).max()
