@@ -72,6 +72,9 @@ constexpr int ids_regs_for(int rows, int a) { return 2 * (rows - a) * (rows - a)
 #ifndef IDS_PREFETCH_AT
 #define IDS_PREFETCH_AT 3                               // body (counted from the chain's root) behind which the next inputs are requested
 #endif
+#ifndef IDS_PREFETCH_AT_F64
+#define IDS_PREFETCH_AT_F64 0                           // fp64: at the root, when every other body of the sweep is done
+#endif
 #ifndef IDS_REG_ENTRIES_MAX
 #define IDS_REG_ENTRIES_MAX 36                          // entries a lane may keep in registers during the sweep
 #endif
@@ -227,7 +230,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
       if constexpr (grp_has(rt, j)) { qv[j] = qn[j]; qdv[j] = qdn[j]; qddv[j] = qddn[j]; }
     });
     IDS_STAMP(1);
-    sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; if constexpr (grp_has(rt, j)) tr[j] = make_trig<j>(qv[j]); });
+    sfor<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (grp_has(rt, j)) tr[j] = make_trig<j>(qv[j]);
+      // fp64: one joint's sin / cos at a time (interleaved, the seven polynomial chains cost 30-110 spilled registers)
+      if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);
+    });
     IDS_STAMP(2);
     // issues the loads of what comes next: the next group of this tile, else the first group of the next tile
     auto prefetch = [&]() {
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     // ---- forward: world kinematics of the chain (:1413-1434) ------------------------------------
     T Rm[3][3], pw[3], v[6], a[6];          // state of the current body: R (body -> world), origin, v, a
     sfor<row0, row0 + rows>([&](auto J) {
+      if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);   // fp64: body steps are not interleaved (register peak)
       constexpr int j = decltype(J)::value;
       constexpr int k = AXIS[j], ka = (k + 1) % 3, kb = (k + 2) % 3;
       constexpr bool root = PARENT[j] < 0;
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     SymB<T> SC;
     T pmC[6], fC[6];
     sfor_down<row0, row0 + rows>([&](auto J) {
+      if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);   // fp64: body steps are not interleaved (register peak)
       constexpr int j = decltype(J)::value;
       constexpr int k = AXIS[j], ka = (k + 1) % 3, kb = (k + 2) % 3;
       // tile slot of entry (row r, column c) while body j is being processed: bodies >= rs write the
@@ -518,7 +528,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
       });
       // inputs of what comes next: issued late in the sweep, when the registers of the bodies already
       // processed are free (bodies and the epilogue still lie between these loads and their first use)
-      if constexpr (!FDG && j == row0 + (rows > IDS_PREFETCH_AT ? IDS_PREFETCH_AT : rows - 1)) prefetch();
+      // (fp64, one wave per SIMD at 512 VGPRs: the 3 n values in flight are 6 n registers -- requested two bodies later)
+      constexpr int PF_AT = sizeof(T) == 8 ? IDS_PREFETCH_AT_F64 : IDS_PREFETCH_AT;
+      if constexpr (!FDG && j == row0 + (rows > PF_AT ? PF_AT : rows - 1)) prefetch();
       if constexpr (j == last && ids_leaf_parks(row0, rows, ra)) {
         asm volatile("" ::: "memory");
         tr[j].s = my[ids_leaf_slot(row0, rows, ra, 0)]; tr[j].c = my[ids_leaf_slot(row0, rows, ra, 1)];

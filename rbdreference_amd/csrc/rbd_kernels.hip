@@ -1276,10 +1276,18 @@ constexpr bool GRAD_USE_IDSVA = GRAD_IDSVA_OK;
 // world-frame kernel (rbd_idsva_tree.h) in fp32; every eligible robot can be put on it with
 // rbd_set_option(RBD_OPT_GRAD_KERNEL, RBD_GRAD_KERNEL_TREE) (tests, experiments).
 constexpr bool GRAD_TREE_DEFAULT = GRAD_TREE_OK && !GRAD_USE_IDSVA && !GRAD_ACC_IN_REGS;
-// The one-lane chain kernel is an fp32 kernel: in fp64 its 18 n live world-frame values need more than
-// 512 VGPRs (94 spills at n = 7) and the two-lane column kernel is 6 % faster (iiwa, B = 262 144).
+// The one-lane chain kernel in fp64 (round 3): one wave per SIMD -- 476-486 VGPRs for a 7-body chain, no scratch, since the
+// backward sweep recomputes the rotations instead of keeping them -- and 1.58x the two-lane column kernel (iiwa,
+// B = 1 048 576: 310 vs 489 us, identical to 1.5e-15).  Chains of up to 7 bodies: an 8th would not fit 512 VGPRs.
+// RBD_NO_F64_CHAIN restores the column kernel (experiments).  The fused forward_dynamics_grad epilogue (FDG) stays fp32.
 template <class T>
+#ifdef RBD_NO_F64_CHAIN
 constexpr bool grad_chain_kernel() { return GRAD_USE_IDSVA && sizeof(T) == 4; }
+#else
+constexpr bool grad_chain_kernel() { return GRAD_USE_IDSVA && (sizeof(T) == 4 || grad_max_rows() <= 7); }
+#endif
+template <class T>
+constexpr bool grad_chain_fdg() { return GRAD_USE_IDSVA && sizeof(T) == 4; }
 #endif  // RBD_NEED_GRAD
 
 // ---------------------------------------------------------------------------------------------
@@ -2557,7 +2565,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   if (rc != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
-  if constexpr (grad_chain_kernel<T>() && grad_max_rows() == N) {
+  if constexpr (grad_chain_fdg<T>() && grad_max_rows() == N) {
     return idsva_launch<T, true, true>(q, qd, (const T*)qdd_buf, gravity, 0, B, (T*)nullptr, dqdd_du, stream, (const T*)Mi);
   } else if constexpr (GRAD_ACC_IN_REGS) {
     return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);

@@ -52,7 +52,7 @@ def main():
             continue
         print(f"{dem:58s} vgpr={r.get('vgpr_count','?'):>4} agpr={r.get('agpr_count','?'):>3} sgpr={r.get('sgpr_count','?'):>3} "
               f"scratch={r.get('private_segment_fixed_size','?'):>5} lds={r.get('group_segment_fixed_size','?'):>6} "
-              f"spill={r.get('vgpr_spill_count','?')}")
+              f"spill={r.get('vgpr_spill_count','?')} sgpr_spill={r.get('sgpr_spill_count','?')}")
 
 
 if __name__ == "__main__":
