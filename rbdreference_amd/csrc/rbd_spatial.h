@@ -291,7 +291,9 @@ RBD_DEV void sincos_core_(float q, float* s, float* c) {                      //
   *c = __builtin_bit_cast(float, cc);
 }
 RBD_DEV void sincos_(float q, float* s, float* c) {
-  if (__builtin_expect(__builtin_fabsf(q) > 8192.0f, 0)) { sincosf(q, s, c); return; }
+  // WAVE-UNIFORM branch (ballot over the active lanes), not a lane-masked one: see the fp64 routine below for what a
+  // lane-masked branch around a library routine cost.  Any lane beyond the range (or non-finite) sends its wave to sincosf.
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(q) <= 8192.0f)) != 0, 0)) { sincosf(q, s, c); return; }
   sincos_core_(q, s, c);
 }
 // fp64: own three-constant Cody-Waite reduction (pi/2 = 33 + 33 + 53 bits: k * P1 and k * P2 are exact for |k| < 2^20) and
