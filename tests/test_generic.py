@@ -234,3 +234,57 @@ def test_generic_argument_errors_and_handle_lifetime():
     assert lib.rbd_g_fd_workspace_bytes(h, 4, 4, 0) > 0 and lib.rbd_g_fd_workspace_bytes(h, 4, 4, 1) > lib.rbd_g_fd_workspace_bytes(h, 4, 4, 0)
     gm.close()
     assert not gm._handles
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_generic_random_robots_vs_oracle(seed):
+    """Robots drawn at random -- 2 to 24 bodies, random forests, revolute and prismatic joints about all three axes,
+    dense joint frames -- need no compilation on the model-handle library: rnea, rnea_grad (damped), minv and
+    forward_dynamics against the CPU oracle in fp64, rnea_grad in fp32."""
+    from oracle import rbd_oracle as orc
+    from rbdreference_amd import RBDReference
+    from rbdreference_amd.robot import random_tree
+    torch = _torch()
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(2, 25))
+    parents = [-1] + [int(rng.integers(max(-1, i - 5), i)) for i in range(1, n)]
+    robot = random_tree(parents, seed=7000 + seed, prismatic_every=int(rng.integers(0, 5)), name=f"fuzz_{seed}_n{n}")
+    rbd = RBDReference(robot, build=False, generic="only"); om = orc.model_from_robot(robot)
+    B = 67
+    q = rng.uniform(-np.pi, np.pi, (B, n)); qd = rng.uniform(-1, 1, (B, n)); qdd = rng.uniform(-1, 1, (B, n))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    c_ref, dc_ref = orc.rnea_grad(om, q, qd, qdd, return_c=True, USE_VELOCITY_DAMPING=True)
+    c, dc = rbd.rnea_grad(tq, tqd, tqdd, return_c=True, USE_VELOCITY_DAMPING=True)
+    check("dc_du (damped)", dc, dc_ref, TOL64); check("c", c, c_ref, TOL64)
+    check("dc_du qdd=None", rbd.rnea_grad(tq, tqd), orc.rnea_grad(om, q, qd), TOL64)
+    _, v, a, f = rbd.rnea(tq, tqd, tqdd)
+    _, vr, ar, fr = orc.rnea(om, q, qd, qdd)
+    check("v", v, vr, TOL64); check("a", a, ar, TOL64); check("f", f, fr, TOL64)
+    check("Minv", rbd.minv(tq), orc.minv(om, q), 1e-9)
+    check("forward_dynamics", rbd.forward_dynamics(tq, tqd, tqdd), orc.forward_dynamics(om, q, qd, qdd), 1e-8)
+    sq, sqd, sqdd = dev_tensors(torch.float32, q, qd, qdd)
+    check("dc_du f32", rbd.rnea_grad(sq, sqd, sqdd), orc.rnea_grad(om, q, qd, qdd), TOL32)
+
+
+@pytest.mark.parametrize("name", all_golden_names() + fb_golden_names())
+def test_specialised_and_generic_libraries_agree_on_4096_rows(name, prec):
+    """Two independent implementations of the same recursions -- the robot's own kernels (world-frame identities,
+    compile-time model) and the model-handle kernels (the reference's column recursions, run-time model) -- on 4 096
+    seeded rows per robot and precision: rnea, rnea_grad, minv agree to the tolerance of the precision.  Neither is the
+    checker of the other elsewhere (goldens and oracle are); here each covers the other on rows no fixture holds."""
+    from rbdreference_amd import RBDReference
+    dt, tol = prec
+    torch = _torch()
+    spec = RBDReference(make_robot(name), build=False, generic="never"); gen = generic_for(name)
+    B = 4096; nv = spec.nv
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    q, qd, qdd = dev_tensors(dt, rng.uniform(-np.pi, np.pi, (B, nv)), rng.uniform(-1, 1, (B, nv)), rng.uniform(-1, 1, (B, nv)))
+    t2 = 4 * tol
+    cs, vs, as_, fs = spec.rnea(q, qd, qdd); cg, vg, ag, fg = gen.rnea(q, qd, qdd)
+    check("c", cg, cs.double().cpu().numpy(), t2); check("f", fg, fs.double().cpu().numpy(), t2)
+    check("v", vg, vs.double().cpu().numpy(), t2); check("a", ag, as_.double().cpu().numpy(), t2)
+    if not (spec.model.floating and spec.n < 6):
+        check("dc_du", gen.rnea_grad(q, qd, qdd), spec.rnea_grad(q, qd, qdd).double().cpu().numpy(), t2)
+    Ms = spec.minv(q).double().cpu().numpy()
+    cond = np.array([np.linalg.cond(M) for M in Ms[:64]]).max()
+    check("Minv", gen.minv(q), Ms, max(t2, 8 * (2.0 ** -24 if dt == torch.float32 else 2.0 ** -53) * cond))
