@@ -410,6 +410,26 @@ def main():
             ms = time_extra_ms(lambda: rbd.forward_dynamics_grad(q, qd, qdd), 10, 2)
             extra["iiwa_forward_dynamics_grad_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3)}
             try:
+                # the reference's own arithmetic (fp64) on the headline robot, and the first-use path (the model-handle
+                # library, include/rbd_generic.h: no per-robot compilation) on one rank's share of the batch
+                q64, qd64, qdd64 = q.double(), qd.double(), qdd.double()
+                dc64 = torch.empty((Bq, 7, 14), dtype=torch.float64, device=dev)
+                ms = time_extra_ms(lambda: rbd.rnea_grad(q64, qd64, qdd64, out=dc64), 5, 2)
+                extra["iiwa_rnea_grad_B%d_f64_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
+                                                             "alg_GBps": Bq * (21 + 98) * 8 / (ms * 1e-3) / 1e9,
+                                                             "kernel": rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 8, Bq)}
+                del q64, qd64, qdd64, dc64
+                gen = RBDReference(robot, build=False, generic="only")
+                Bg = 131072
+                dcg = torch.empty((Bg, 7, 14), dtype=torch.float32, device=dev)
+                ms = time_extra_ms(lambda: gen.rnea_grad(q[:Bg], qd[:Bg], qdd[:Bg], out=dcg), 3, 1)
+                extra["first_use_model_handle_library_iiwa_rnea_grad_B%d_f32" % Bg] = {
+                    "ms_per_call": ms, "evals_per_s": Bg / (ms * 1e-3), "kernel": gen._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, Bg),
+                    "note": "librbd_generic.so: the robot is a run-time table; serves a never-built robot until its own library is ready"}
+                del gen, dcg
+            except Exception as e:
+                extra["f64_or_generic_error"] = repr(e)
+            try:
                 # the same kernel on a 7-chain with DENSE joint frames and inertias (random_chain_n7): what
                 # the iiwa-like robot's structural zeros / unit entries are worth
                 from __graft_entry__ import test_robots
