@@ -738,6 +738,7 @@ int fd_host(const rbd_model* m, const T* q, const T* qd, const T* u, T grav, lon
   T* dc = (T*)((char*)Mi + align256((size_t)B * n * n * sizeof(T)));
   if (int rc = rnea_host<T>(m, q, qd, nullptr, grav, B, c, nullptr, nullptr, nullptr, stream)) return rc;   // c(q, qd)  (:1372)
   if (int rc = minv_host<T>(m, q, B, 1, Mi, stream)) return rc;                                              // (:1373)
+  if ((B * 2LL * n * n + 255) / 256 > 0x7fffffffLL) return fail(RBD_G_ERR_ARG, "%s: B = %lld exceeds the grid", who, (long long)B);
   {
     const long long tot = B * n;
     hipLaunchKernelGGL((g_fd_apply_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, B, Mi, u, c, qdd);

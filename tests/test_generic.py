@@ -288,3 +288,28 @@ def test_specialised_and_generic_libraries_agree_on_4096_rows(name, prec):
     Ms = spec.minv(q).double().cpu().numpy()
     cond = np.array([np.linalg.cond(M) for M in Ms[:64]]).max()
     check("Minv", gen.minv(q), Ms, max(t2, 8 * (2.0 ** -24 if dt == torch.float32 else 2.0 ** -53) * cond))
+
+
+def test_the_ctypes_stub_of_integration_md_runs_as_written():
+    """INTEGRATION.md §2b is what a maintainer of the reference would paste: execute that code block verbatim
+    (rbd_model_create from the robot's getters, rbd_g_rnea_grad_f64 through the handle) and hold it to the oracle."""
+    import ctypes
+    import os
+    import re
+    from conftest import ROOT
+    from oracle import rbd_oracle as orc
+    from rbdreference_amd.build import generic_lib_path
+    torch = _torch()
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", txt, flags=re.S) if "class _HipGeneric" in b)
+    ns = {"ctypes": ctypes, "np": np}
+    exec(block, ns)                                        # the document's own text
+    robot = make_robot("iiwa_like")
+    h = ns["_HipGeneric"](robot, lib_path=generic_lib_path(), device=0)
+    B, n = 50, h.n
+    rng = np.random.default_rng(0)
+    q, qd, qdd = rng.uniform(-3, 3, (B, n)), rng.uniform(-1, 1, (B, n)), rng.uniform(-1, 1, (B, n))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    dc = torch.empty((B, n, 2 * n), dtype=torch.float64, device="cuda:0")
+    assert h.L.rbd_g_rnea_grad_f64(h.h, tq.data_ptr(), tqd.data_ptr(), tqdd.data_ptr(), -9.81, 0, B, None, dc.data_ptr(), None) == 0
+    check("dc_du through the documented stub", dc, orc.rnea_grad(orc.model_from_robot(robot), q, qd, qdd), TOL64)
