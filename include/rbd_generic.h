@@ -84,6 +84,15 @@ int rbd_g_rnea_grad_f32(const rbd_model*, const float* q, const float* qd, const
 int rbd_g_rnea_grad_f64(const rbd_model*, const double* q, const double* qd, const double* qdd, double gravity,
                         int use_damping, int64_t B, double* c, double* dc_du, void* stream);
 
+/* rbd_g_rnea_grad has two kernels that compute the same result: COLUMNS, the reference's column recursions (any robot),
+ * and WORLD, the world-frame identities the specialised libraries use (fixed base, revolute joints with S = (axis; 0),
+ * rigid-body inertias: 3-4x faster).  AUTO picks WORLD where it applies.  Process-wide, thread-safe (tests run both). */
+#define RBD_G_GRAD_KERNEL_AUTO 0
+#define RBD_G_GRAD_KERNEL_COLUMNS 1
+#define RBD_G_GRAD_KERNEL_WORLD 2
+int rbd_g_set_grad_kernel(int which);
+int rbd_g_grad_kernel_of(const rbd_model* m);   /* the kernel rbd_g_rnea_grad would run for this model now */
+
 /* Replaces RBDReference.minv (:785): Minv [B,n,n]; output_dense = 0 leaves a zero strict lower triangle. */
 int rbd_g_minv_f32(const rbd_model*, const float* q, int64_t B, int output_dense, float* Minv, void* stream);
 int rbd_g_minv_f64(const rbd_model*, const double* q, int64_t B, int output_dense, double* Minv, void* stream);

@@ -12,6 +12,7 @@
 // This is the first-use path (no compiler, no wait); the specialised per-robot kernels (rbd_kernels.hip) are the fast path.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -37,6 +38,10 @@ struct DevModel {
   T X0[MB][36], Xs[MB][36], Xc[MB][36];
   T I[MB][36];
   T damping[MB];
+  // world-frame gradient kernel (g_rnea_grad_world_kernel): valid when every joint is revolute with S = (axis; 0) and
+  // every inertia has rigid-body form; then mass / centre of mass / rotational inertia about it, per body
+  int world_ok;
+  T mass[MB], com[MB][3], Ic[MB][6], sa[MB][3];
 };
 
 GDEV void sincos_g(float x, float* s, float* c) { sincosf(x, s, c); }
@@ -414,6 +419,237 @@ __global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __re
   }
 }
 
+
+// ---- world-frame gradient kernel for all-revolute robots ---------------------------------------------------------------
+// The first-order identities of the reference's IDSVA scheme (/root/reference/RBDReference.py:1413-1484), the ones the
+// specialised kernels evaluate (rbd_world.h), with the robot as a run-time table: ~500 operations per body and ~40 per
+// (body, ancestor) pair instead of ~300 per pair, and a third of the private-memory traffic of the column recursion
+// above.  They reproduce RBDReference.rnea_grad (:1345-1368) for revolute joints (the reference's fxS term is the true
+// derivative only there, :1292-1294), so robots with a prismatic joint keep g_rnea_grad_kernel.
+template <class T>
+struct GInertia { T m, h[3], I[6]; };           // rigid inertia about the world origin: mass, m c, Ibar (xx xy xz yy yz zz)
+template <class T>
+struct GSym { T TL[6], G[3]; };                  // symmetric part of the body-level Coriolis matrix: [[TL, G^x], [G^x^T, 0]]
+template <class T>
+struct GComp { GInertia<T> IC; GSym<T> SC; T pm[6], f[6]; };
+constexpr int GCOMP = 31;
+
+template <class T>
+GDEV void gin_apply(const GInertia<T>& R, const T* x, T (&y)[6]) {
+  const T* w = x; const T* u = x + 3;
+  T hu[3], hw[3];
+  cross3g(R.h, u, hu);
+  cross3g(R.h, w, hw);
+  y[0] = fma(R.I[0], w[0], fma(R.I[1], w[1], fma(R.I[2], w[2], hu[0])));
+  y[1] = fma(R.I[1], w[0], fma(R.I[3], w[1], fma(R.I[4], w[2], hu[1])));
+  y[2] = fma(R.I[2], w[0], fma(R.I[4], w[1], fma(R.I[5], w[2], hu[2])));
+  y[3] = fma(R.m, u[0], -hw[0]); y[4] = fma(R.m, u[1], -hw[1]); y[5] = fma(R.m, u[2], -hw[2]);
+}
+template <class T>
+GDEV void gsym_apply(const GSym<T>& S, const T* x, T (&y)[6]) {
+  const T* a = x; const T* b = x + 3;
+  T gb[3], ga[3];
+  cross3g(S.G, b, gb);
+  cross3g(S.G, a, ga);
+  y[0] = fma(S.TL[0], a[0], fma(S.TL[1], a[1], fma(S.TL[2], a[2], gb[0])));
+  y[1] = fma(S.TL[1], a[0], fma(S.TL[3], a[1], fma(S.TL[4], a[2], gb[1])));
+  y[2] = fma(S.TL[2], a[0], fma(S.TL[4], a[1], fma(S.TL[5], a[2], gb[2])));
+  y[3] = -ga[0]; y[4] = -ga[1]; y[5] = -ga[2];
+}
+
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_rnea_grad_world_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
+                                                               const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
+                                                               int use_damping, long long B, T* __restrict__ c_out,
+                                                               T* __restrict__ dc) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T Sv[NMAX][6], Pd[NMAX][6], Pdd[NMAX][6], vw[NMAX][6], aw[NMAX][6], Rw[NMAX][9], pw[NMAX][3];
+  T Cm[NMAX][GCOMP];
+  // ---- root -> leaves: world kinematics (:1413-1434) and every body's own inertia terms (:1436-1440) ----
+  for (int i = 0; i < n; ++i) {
+    T f1, f2, X[36];
+    joint_fun(0, q[b * n + i], f1, f2);
+    build_X(m, i, f1, f2, X);
+    const int p = m->parent[i];
+    const T qdi = qd[b * n + i], qddi = qdd ? qdd[b * n + i] : T(0);
+    // X = [[E, 0], [-E r^x, E]]: R = R_p E^T, origin = p_p + R_p r with r^x = -E^T (lower-left block)
+    T r3[3];
+    r3[0] = -(X[0 * 6 + 2] * X[3 * 6 + 1] + X[1 * 6 + 2] * X[4 * 6 + 1] + X[2 * 6 + 2] * X[5 * 6 + 1]);
+    r3[1] = -(X[0 * 6 + 0] * X[3 * 6 + 2] + X[1 * 6 + 0] * X[4 * 6 + 2] + X[2 * 6 + 0] * X[5 * 6 + 2]);
+    r3[2] = -(X[0 * 6 + 1] * X[3 * 6 + 0] + X[1 * 6 + 1] * X[4 * 6 + 0] + X[2 * 6 + 1] * X[5 * 6 + 0]);
+    T R[9], pp[3];
+    if (p < 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[a * 3 + c] = X[c * 6 + a];
+        pp[a] = r3[a];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const T ra0 = Rw[p][a * 3], ra1 = Rw[p][a * 3 + 1], ra2 = Rw[p][a * 3 + 2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[a * 3 + c] = fma(ra0, X[c * 6 + 0], fma(ra1, X[c * 6 + 1], ra2 * X[c * 6 + 2]));
+        pp[a] = fma(ra0, r3[0], fma(ra1, r3[1], fma(ra2, r3[2], pw[p][a])));
+      }
+    }
+    T S[6], psid[6], psidd[6], v[6], a[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) S[r] = fma(R[r * 3], m->sa[i][0], fma(R[r * 3 + 1], m->sa[i][1], R[r * 3 + 2] * m->sa[i][2]));
+    cross3g(pp, S, S + 3);
+    if (p < 0) {            // v_p = 0, a_p = [0,0,0,0,0,-GRAVITY]  (:1417-1420)
+      T ap[6] = {T(0), T(0), T(0), T(0), T(0), -grav};
+      crm_mul(ap, S, psidd);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { psid[r] = T(0); v[r] = S[r] * qdi; a[r] = fma(S[r], qddi, ap[r]); }
+    } else {
+      T t1[6], t2[6], vp[6], ap[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { vp[r] = vw[p][r]; ap[r] = aw[p][r]; }
+      crm_mul(vp, S, psid);                                 // psid  = v_p x S                 (:1431)
+      crm_mul(ap, S, t1);                                   // psidd = a_p x S + v_p x psid    (:1432)
+      crm_mul(vp, psid, t2);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        psidd[r] = t1[r] + t2[r];
+        v[r] = fma(S[r], qdi, vp[r]);                                       // (:1433)
+        a[r] = fma(S[r], qddi, fma(psid[r], qdi, ap[r]));                   // (:1430, :1434)
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { Sv[i][r] = S[r]; Pd[i][r] = psid[r]; Pdd[i][r] = psidd[r]; vw[i][r] = v[r]; aw[i][r] = a[r]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rw[i][k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pw[i][k] = pp[k];
+    // the body's own terms about the world origin
+    GComp<T> L;
+    T cw[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cw[r] = fma(R[r * 3], m->com[i][0], fma(R[r * 3 + 1], m->com[i][1], fma(R[r * 3 + 2], m->com[i][2], pp[r])));
+    L.IC.m = m->mass[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) L.IC.h[r] = L.IC.m * cw[r];
+    {
+      const T i0 = m->Ic[i][0], i1 = m->Ic[i][1], i2 = m->Ic[i][2], i3 = m->Ic[i][3], i4 = m->Ic[i][4], i5 = m->Ic[i][5];
+      T A[9];                                               // A = R Ic
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        A[r * 3 + 0] = fma(R[r * 3], i0, fma(R[r * 3 + 1], i1, R[r * 3 + 2] * i2));
+        A[r * 3 + 1] = fma(R[r * 3], i1, fma(R[r * 3 + 1], i3, R[r * 3 + 2] * i4));
+        A[r * 3 + 2] = fma(R[r * 3], i2, fma(R[r * 3 + 1], i4, R[r * 3 + 2] * i5));
+      }
+      const T cc = fma(cw[0], cw[0], fma(cw[1], cw[1], cw[2] * cw[2]));
+      const int IR[6] = {0, 0, 0, 1, 1, 2}, IC_[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int r = IR[e], c = IC_[e];
+        T x = fma(A[r * 3], R[c * 3], fma(A[r * 3 + 1], R[c * 3 + 1], A[r * 3 + 2] * R[c * 3 + 2]));
+        const T mcc = L.IC.h[r] * cw[c];
+        x += (r == c) ? fma(L.IC.m, cc, -mcc) : -mcc;
+        L.IC.I[e] = x;
+      }
+    }
+    T Ia[6];
+    gin_apply(L.IC, v, L.pm);
+    gin_apply(L.IC, a, Ia);
+    crf_mul(v, L.pm, L.f);                                  // f = I a + v x* (I v)   (:1440)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) L.f[r] += Ia[r];
+    {
+      const T* w = v; const T* u = v + 3;
+      const T If[9] = {L.IC.I[0], L.IC.I[1], L.IC.I[2], L.IC.I[1], L.IC.I[3], L.IC.I[4], L.IC.I[2], L.IC.I[4], L.IC.I[5]};
+      T K[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const T col[3] = {If[c], If[3 + c], If[6 + c]};
+        T o[3];
+        cross3g(w, col, o);
+        K[c] = o[0]; K[3 + c] = o[1]; K[6 + c] = o[2];
+      }
+      const T uh2 = T(2) * fma(u[0], L.IC.h[0], fma(u[1], L.IC.h[1], u[2] * L.IC.h[2]));
+      const int IR[6] = {0, 0, 0, 1, 1, 2}, IC_[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int r = IR[e], c = IC_[e];
+        T x = K[r * 3 + c] + K[c * 3 + r];
+        x = fma(-L.IC.h[r], u[c], fma(-u[r], L.IC.h[c], x));
+        if (r == c) x += uh2;
+        L.SC.TL[e] = x;
+      }
+      T g[3];
+      cross3g(w, L.IC.h, g);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) L.SC.G[r] = fma(L.IC.m, u[r], g[r]);
+    }
+    Cm[i][0] = L.IC.m;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { Cm[i][1 + r] = L.IC.h[r]; Cm[i][16 + r] = L.SC.G[r]; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { Cm[i][4 + r] = L.IC.I[r]; Cm[i][10 + r] = L.SC.TL[r]; Cm[i][19 + r] = L.pm[r]; Cm[i][25 + r] = L.f[r]; }
+  }
+  // ---- leaves -> root: composites (:1446-1448), c, t-vectors (:1481-1484), every (body, ancestor) pair ----
+  T* row = dc + b * 2 * n * n;
+  for (int j = n - 1; j >= 0; --j) {
+    GComp<T> C;
+    C.IC.m = Cm[j][0];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { C.IC.h[r] = Cm[j][1 + r]; C.SC.G[r] = Cm[j][16 + r]; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { C.IC.I[r] = Cm[j][4 + r]; C.SC.TL[r] = Cm[j][10 + r]; C.pm[r] = Cm[j][19 + r]; C.f[r] = Cm[j][25 + r]; }
+    const int p = m->parent[j];
+    if (p >= 0) {
+#pragma unroll
+      for (int k = 0; k < GCOMP; ++k) Cm[p][k] += Cm[j][k];
+    }
+    T S[6], psid[6], psidd[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { S[r] = Sv[j][r]; psid[r] = Pd[j][r]; psidd[r] = Pdd[j][r]; }
+    if (c_out) c_out[b * n + j] = dot6g(S, C.f);
+    T t1[6], t2[6], t3[6], t4[6];
+    {
+      T y3[6], s1[6], z1[6], zf[6], y2[6], s2[6], z2[6];
+      gin_apply(C.IC, S, t1);
+      gin_apply(C.IC, psidd, y3);
+      gsym_apply(C.SC, S, s1);
+      crf_mul(S, C.pm, z1);
+      crf_mul(S, C.f, zf);
+      gin_apply(C.IC, psid, y2);
+      gsym_apply(C.SC, psid, s2);
+      crf_mul(psid, C.pm, z2);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        t4[r] = s1[r] - z1[r];
+        t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
+        t2[r] = fma(T(2), y2[r], s1[r] + z1[r]);
+      }
+    }
+    const unsigned long long anc = m->anc[j];
+    for (int c = 0; c < n; ++c) {
+      if ((anc >> c) & 1ull) {                              // c == j or an ancestor of j
+        T Sc[6], Pc[6], Pcc[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { Sc[r] = Sv[c][r]; Pc[r] = Pd[c][r]; Pcc[r] = Pdd[c][r]; }
+        T dq = dot6g(t4, Pc) + dot6g(t1, Pcc);
+        T dqd = fma(T(2), dot6g(t1, Pc), dot6g(t4, Sc));
+        if (c == j && use_damping) dqd += m->damping[j];    // (:1336-1341)
+        row[j * 2 * n + c] = dq;
+        row[j * 2 * n + n + c] = dqd;
+        if (c != j) {
+          row[c * 2 * n + j] = dot6g(Sc, t3);
+          row[c * 2 * n + n + j] = dot6g(Sc, t2);
+        }
+      } else if (!((m->anc[c] >> j) & 1ull)) {              // unrelated bodies: structural zeros
+        row[j * 2 * n + c] = T(0);
+        row[j * 2 * n + n + c] = T(0);
+      }
+    }
+  }
+}
+
 // in-place inverse of a symmetric positive definite 6 x 6 (Gauss-Jordan, no pivoting needed)
 template <class T>
 GDEV void inv6_spd(T (&A)[36]) {
@@ -592,6 +828,8 @@ __global__ void __launch_bounds__(256) g_neg_mm_kernel(int n, long long B, const
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
+std::atomic<int> g_grad_kernel_option{0};
+
 char* err_buf() {
   static thread_local char buf[512] = "";
   return buf;
@@ -615,6 +853,7 @@ struct rbd_model {
   int n;        // bodies
   int fb;       // floating base
   int nv;       // velocities: n, or n + 5 with a floating base
+  int world_ok; // the world-frame gradient kernel serves this robot
   rbdg::DevModel<float>* d32;
   rbdg::DevModel<double>* d64;
 };
@@ -647,6 +886,36 @@ void fill(DevModel<T>& d, const rbd_model_desc* s) {
     }
     d.damping[i] = (T)s->damping[i];
   }
+  // world-frame kernel: revolute joints with S = (axis; 0), rigid-body inertias
+  bool ok = !d.fb;
+  for (int i = 0; i < s->n && ok; ++i) {
+    const double* I = s->I + i * 36;
+    const double* S = s->S + i * 6;
+    const double mass = I[3 * 6 + 3];
+    double scale = 0;
+    for (int k = 0; k < 36; ++k) scale = std::fmax(scale, std::fabs(I[k]));
+    const double tol = 1e-12 * std::fmax(scale, 1.0);
+    ok = s->joint_type[i] == 0 && S[3] == 0 && S[4] == 0 && S[5] == 0 && mass > 0;
+    // [[Io, h^x], [h^x^T, m 1]] with h^x = [[0,-h2,h1],[h2,0,-h0],[-h1,h0,0]]
+    const double h0 = I[2 * 6 + 4], h1 = I[0 * 6 + 5], h2 = I[1 * 6 + 3];
+    const double U[9] = {0, -h2, h1, h2, 0, -h0, -h1, h0, 0};
+    for (int r = 0; r < 3 && ok; ++r)
+      for (int c = 0; c < 3 && ok; ++c) {
+        ok = std::fabs(I[r * 6 + 3 + c] - U[r * 3 + c]) <= tol && std::fabs(I[(3 + c) * 6 + r] - U[r * 3 + c]) <= tol &&
+             std::fabs(I[(3 + r) * 6 + 3 + c] - (r == c ? mass : 0.0)) <= tol && std::fabs(I[r * 6 + c] - I[c * 6 + r]) <= tol;
+      }
+    if (!ok) break;
+    const double c0 = h0 / mass, c1 = h1 / mass, c2 = h2 / mass, cc = c0 * c0 + c1 * c1 + c2 * c2;
+    const double cv[3] = {c0, c1, c2};
+    d.mass[i] = (T)mass;
+    for (int r = 0; r < 3; ++r) { d.com[i][r] = (T)cv[r]; d.sa[i][r] = (T)S[r]; }
+    const int IR[6] = {0, 0, 0, 1, 1, 2}, IC_[6] = {0, 1, 2, 1, 2, 2};
+    for (int e = 0; e < 6; ++e) {                          // Ic = Io - m (|c|^2 1 - c c^T)
+      const int r = IR[e], c = IC_[e];
+      d.Ic[i][e] = (T)(I[r * 6 + c] - mass * ((r == c ? cc : 0.0) - cv[r] * cv[c]));
+    }
+  }
+  d.world_ok = ok ? 1 : 0;
 }
 
 int check_call(const rbd_model* m, long long B, const char* who) {
@@ -696,6 +965,16 @@ int grad_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav,
     return fail(RBD_G_ERR_UNSUPPORTED, "rbd_g_rnea_grad: a floating-base robot needs >= 6 bodies (RBDReference.py:1168 raises for fewer)");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
+  const int opt = g_grad_kernel_option.load(std::memory_order_relaxed);
+  if (m->world_ok && opt != RBD_G_GRAD_KERNEL_COLUMNS) {
+    const int n_ = m->n;
+#define WCALL(NM) hipLaunchKernelGGL((g_rnea_grad_world_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
+    if (n_ <= 8) { WCALL(8); } else if (n_ <= 16) { WCALL(16); } else if (n_ <= 32) { WCALL(32); } else { WCALL(64); }
+#undef WCALL
+    hipError_t ew = hipGetLastError();
+    return ew == hipSuccess ? 0 : hip_fail(ew, "rbd_g_rnea_grad (world-frame kernel) launch");
+  }
+  if (opt == RBD_G_GRAD_KERNEL_WORLD) return fail(RBD_G_ERR_UNSUPPORTED, "rbd_g_rnea_grad: the world-frame kernel needs a fixed base, revolute joints and rigid-body inertias");
 #define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
   RBDG_DISPATCH(m, CALL);
 #undef CALL
@@ -792,7 +1071,7 @@ int rbd_model_create(const rbd_model_desc* s, int device, rbd_model** out) {
   if (e != hipSuccess) return hip_fail(e, "rbd_model_create");
   e = hipSetDevice(device);
   if (e != hipSuccess) return hip_fail(e, "rbd_model_create: hipSetDevice");
-  rbd_model* m = new (std::nothrow) rbd_model{device, s->n, s->floating_base ? 1 : 0, s->n + (s->floating_base ? 5 : 0), nullptr, nullptr};
+  rbd_model* m = new (std::nothrow) rbd_model{device, s->n, s->floating_base ? 1 : 0, s->n + (s->floating_base ? 5 : 0), 0, nullptr, nullptr};
   DevModel<float>* h32 = new (std::nothrow) DevModel<float>;
   DevModel<double>* h64 = new (std::nothrow) DevModel<double>;
   int rc = 0;
@@ -800,6 +1079,7 @@ int rbd_model_create(const rbd_model_desc* s, int device, rbd_model** out) {
   if (rc == 0) {
     fill(*h32, s);
     fill(*h64, s);
+    m->world_ok = h64->world_ok;
     if ((e = hipMalloc((void**)&m->d32, sizeof(*h32))) != hipSuccess || (e = hipMalloc((void**)&m->d64, sizeof(*h64))) != hipSuccess ||
         (e = hipMemcpy(m->d32, h32, sizeof(*h32), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(m->d64, h64, sizeof(*h64), hipMemcpyHostToDevice)) != hipSuccess)
@@ -829,6 +1109,16 @@ void rbd_model_destroy(rbd_model* m) {
 }
 int rbd_model_n(const rbd_model* m) { return m ? m->n : 0; }
 int rbd_model_nv(const rbd_model* m) { return m ? m->nv : 0; }
+int rbd_g_set_grad_kernel(int which) {
+  if (which < 0 || which > 2) return rbdg::fail(RBD_G_ERR_ARG, "rbd_g_set_grad_kernel: %d", which);
+  rbdg::g_grad_kernel_option.store(which, std::memory_order_relaxed);
+  return 0;
+}
+int rbd_g_grad_kernel_of(const rbd_model* m) {
+  if (!m) return -1;
+  const int opt = rbdg::g_grad_kernel_option.load(std::memory_order_relaxed);
+  return (m->world_ok && opt != RBD_G_GRAD_KERNEL_COLUMNS) ? RBD_G_GRAD_KERNEL_WORLD : RBD_G_GRAD_KERNEL_COLUMNS;
+}
 
 int rbd_g_rnea_f32(const rbd_model* m, const float* q, const float* qd, const float* qdd, float g, int64_t B, float* c, float* v, float* a, float* f, void* st) {
   return rbdg::rnea_host<float>(m, q, qd, qdd, g, B, c, v, a, f, st);

@@ -18,10 +18,12 @@ from .packer import PackedModel
 
 RBD_G_ABI_VERSION = 1
 RBD_G_MAX_BODIES = 64
+RBD_G_GRAD_KERNEL_AUTO, RBD_G_GRAD_KERNEL_COLUMNS, RBD_G_GRAD_KERNEL_WORLD = 0, 1, 2
 
 # every symbol include/rbd_generic.h declares (tests check the built library exports all of them)
 GENERIC_EXPORTED_SYMBOLS = [
     "rbd_g_abi_version", "rbd_g_last_error", "rbd_model_create", "rbd_model_destroy", "rbd_model_n", "rbd_model_nv",
+    "rbd_g_set_grad_kernel", "rbd_g_grad_kernel_of",
     "rbd_g_rnea_f32", "rbd_g_rnea_f64", "rbd_g_rnea_grad_f32", "rbd_g_rnea_grad_f64",
     "rbd_g_minv_f32", "rbd_g_minv_f64", "rbd_g_fd_workspace_bytes",
     "rbd_g_forward_dynamics_f32", "rbd_g_forward_dynamics_f64",
@@ -50,6 +52,10 @@ def _declare(lib):
     lib.rbd_model_n.argtypes = [c_void_p]
     lib.rbd_model_nv.restype = c_int
     lib.rbd_model_nv.argtypes = [c_void_p]
+    lib.rbd_g_set_grad_kernel.restype = c_int
+    lib.rbd_g_set_grad_kernel.argtypes = [c_int]
+    lib.rbd_g_grad_kernel_of.restype = c_int
+    lib.rbd_g_grad_kernel_of.argtypes = [c_void_p]
     lib.rbd_g_fd_workspace_bytes.restype = c_size_t
     lib.rbd_g_fd_workspace_bytes.argtypes = [c_void_p, c_int64, c_int, c_int]
     for sfx, ft in (("f32", c_float), ("f64", c_double)):
@@ -209,4 +215,8 @@ class GenericModel:
     def kernel_name(self, op: int, elem_size: int) -> str:
         n = self.model.n
         nm = 8 if n <= 8 else 16 if n <= 16 else 32 if n <= 32 else 64
-        return f"{('g_rnea_kernel', 'g_rnea_grad_kernel', 'g_minv_kernel')[op]}<{'float' if elem_size == 4 else 'double'}, {nm}>"
+        name = ('g_rnea_kernel', 'g_rnea_grad_kernel', 'g_minv_kernel')[op]
+        if op == 1 and self._handles:        # (the choice between the two gradient kernels is the library's: ask it)
+            if self.lib.rbd_g_grad_kernel_of(next(iter(self._handles.values()))) == RBD_G_GRAD_KERNEL_WORLD:
+                name = "g_rnea_grad_world_kernel"
+        return f"{name}<{'float' if elem_size == 4 else 'double'}, {nm}>"

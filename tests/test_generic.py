@@ -28,15 +28,30 @@ def prec(request):
     return (torch.float32, TOL32) if request.param == "float32" else (torch.float64, TOL64)
 
 
+@pytest.fixture(params=["auto", "columns"])
+def gkernel(request):
+    """Both gradient kernels of the model-handle library: AUTO (the world-frame kernel where it applies) and the
+    column recursions forced (rbd_g_set_grad_kernel), restored afterwards."""
+    from rbdreference_amd.generic import RBD_G_GRAD_KERNEL_AUTO, RBD_G_GRAD_KERNEL_COLUMNS, load_generic_library
+    lib = load_generic_library()
+    assert lib.rbd_g_set_grad_kernel(RBD_G_GRAD_KERNEL_COLUMNS if request.param == "columns" else RBD_G_GRAD_KERNEL_AUTO) == 0
+    yield request.param
+    lib.rbd_g_set_grad_kernel(RBD_G_GRAD_KERNEL_AUTO)
+
+
 @pytest.mark.parametrize("name", all_golden_names())
-def test_generic_rnea_and_gradient_vs_golden(name, prec):
+def test_generic_rnea_and_gradient_vs_golden(name, prec, gkernel):
     """rbd_g_rnea / rbd_g_rnea_grad against the reference's outputs (RBDReference.py:623-628, :1345-1368): every
-    fixed-base fixture, incl. the prismatic robot (the literal fxS term, :1292-1294), qdd=None and damping."""
+    fixed-base fixture, incl. the prismatic robot (the literal fxS term, :1292-1294), qdd=None and damping; both
+    gradient kernels."""
     from rbdreference_amd._lib import RBD_OP_RNEA_GRAD
     dt, tol = prec
     g = load_golden(name); rbd = generic_for(name)
-    assert rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, 16).startswith("g_rnea_grad_kernel<")
     q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    rbd.rnea(q, qd)                               # (a handle exists from here on: kernel_name asks the library)
+    kn = rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, 16)
+    world = gkernel == "auto" and name != "random_prismatic_n6"
+    assert kn.startswith("g_rnea_grad_world_kernel<" if world else "g_rnea_grad_kernel<"), kn
     c, v, a, f = rbd.rnea(q, qd, qdd)
     assert rbd._lib.served_by_generic()
     check("c", c, g["c"], tol); check("v", v, g["fpass_v"], tol); check("a", a, g["fpass_a"], tol)
