@@ -92,6 +92,10 @@ int rbd_g_rnea_grad_f64(const rbd_model*, const double* q, const double* qd, con
 #define RBD_G_GRAD_KERNEL_WORLD 2
 int rbd_g_set_grad_kernel(int which);
 int rbd_g_grad_kernel_of(const rbd_model* m);   /* the kernel rbd_g_rnea_grad would run for this model now */
+/* How results leave the kernels: 0 AUTO (staged through private memory and an LDS tile into 256-byte runs per
+ * configuration when the launch has >= 1 024 waves -- one per SIMD --, direct 4-byte stores below that), 1 never staged, 2 always
+ * (robots of <= 32 bodies).  The values are the same either way. */
+int rbd_g_set_output_staging(int which);
 
 /* Replaces RBDReference.minv (:785): Minv [B,n,n]; output_dense = 0 leaves a zero strict lower triangle. */
 int rbd_g_minv_f32(const rbd_model*, const float* q, int64_t B, int output_dense, float* Minv, void* stream);

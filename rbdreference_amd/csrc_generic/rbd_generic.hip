@@ -157,6 +157,41 @@ GDEV void base_X(const T (&bt)[9], T (&X)[36]) {
   }
 }
 
+
+// ---- coalesced output: a lane's results wait in private memory, the wave writes them out through an LDS tile ----------
+// A lane owns a configuration, and a configuration's outputs are contiguous in HBM: written as they are formed they
+// are 4-byte stores 2 n^2 (or 6 n, n^2) elements apart between neighbouring lanes -- every 64-byte sector is written
+// sixteen times, partially.  Instead the values collect in a private array and leave KCH per configuration at a time:
+// tile[lane][k] <- private, then consecutive lanes store consecutive elements of one configuration (256-byte runs).
+constexpr int KCH = 64;
+constexpr int KCHP = KCH + 1;                       // odd row stride: the lane-major tile writes hit 64 different banks
+template <int NMAX>
+constexpr bool stage_outputs() { return NMAX <= 32; }   // (64 bodies: 2 * 69^2 values per lane would not fit private memory)
+GDEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+template <class T, class F>
+GDEV void flush_coalesced(F get, int count, T* __restrict__ gdst, long long cfg_stride, int nvalid, T* tile, int lane) {
+  for (int k0 = 0; k0 < count; k0 += KCH) {
+    const int kc = count - k0 < KCH ? count - k0 : KCH;
+    for (int k = 0; k < kc; ++k) tile[lane * KCHP + k] = get(k0 + k);
+    wave_sync();
+    for (int idx = lane; idx < nvalid * kc; idx += 64) {
+      const int cfg = idx / kc, k = idx - cfg * kc;
+      gdst[cfg * cfg_stride + k0 + k] = tile[cfg * KCHP + k];
+    }
+    wave_sync();
+  }
+}
+// this lane's configuration: the block's last wave repeats its last row in the lanes beyond the batch (all 64 lanes
+// take part in the flush; only `nvalid` configurations are stored)
+#define RBDG_LANE_CONFIG()                                                              \
+  const long long b0 = (long long)blockIdx.x * 64;                                      \
+  const int lane = threadIdx.x;                                                         \
+  const int nvalid = (int)(B - b0 < 64 ? B - b0 : 64);                                  \
+  const long long b = b0 + (lane < nvalid ? lane : nvalid - 1)
+
 template <class T, int NMAX>
 struct RneaState {
   T v[NMAX][6], a[NMAX][6], f[NMAX][6];
@@ -262,13 +297,23 @@ template <class T, int NMAX, bool FB>
 __global__ void __launch_bounds__(64) g_rnea_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
                                                     const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
                                                     long long B, T* __restrict__ c, T* __restrict__ v,
-                                                    T* __restrict__ a, T* __restrict__ f) {
-  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+                                                    T* __restrict__ a, T* __restrict__ f, int stage_rt) {
+  RBDG_LANE_CONFIG();
   const int n = m->n, nv = n + (FB ? 5 : 0);
   RneaState<T, NMAX> st;
-  rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st, c + b * nv,
-                           v ? v + b * 6 * n : nullptr, a ? a + b * 6 * n : nullptr, f ? f + b * 6 * n : nullptr);
+  if (stage_outputs<NMAX>() && stage_rt) {
+    __shared__ T tile[64 * KCHP];
+    T cb[NMAX + 5], vb[6 * NMAX], ab[6 * NMAX], fb[6 * NMAX];
+    rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st, cb,
+                             v ? vb : nullptr, a ? ab : nullptr, f ? fb : nullptr);
+    flush_coalesced([&](int k) { return cb[k]; }, nv, c + b0 * nv, nv, nvalid, tile, lane);
+    if (v) flush_coalesced([&](int k) { return vb[k]; }, 6 * n, v + b0 * 6 * n, 6 * n, nvalid, tile, lane);
+    if (a) flush_coalesced([&](int k) { return ab[k]; }, 6 * n, a + b0 * 6 * n, 6 * n, nvalid, tile, lane);
+    if (f) flush_coalesced([&](int k) { return fb[k]; }, 6 * n, f + b0 * 6 * n, 6 * n, nvalid, tile, lane);
+  } else {
+    rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st, c + b * nv,
+                             v ? v + b * 6 * n : nullptr, a ? a + b * 6 * n : nullptr, f ? f + b * 6 * n : nullptr);
+  }
 }
 
 // df = I da + crf(dv)(I v) + crf(v)(I dv)   (:1179-1185, :1247-1252)
@@ -299,16 +344,19 @@ template <class T, int NMAX, bool FB>
 __global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
                                                          const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
                                                          int use_damping, long long B, T* __restrict__ c,
-                                                         T* __restrict__ dc) {
-  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+                                                         T* __restrict__ dc, int stage_rt) {
+  RBDG_LANE_CONFIG();
   constexpr int OFF = FB ? 5 : 0;
+  constexpr bool STAGEC = stage_outputs<NMAX>();
+  const bool STAGE = STAGEC && stage_rt;
   const int n = m->n, nv = n + OFF;
   RneaState<T, NMAX> st;
-  rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st, c ? c + b * nv : nullptr,
-                           (T*)nullptr, (T*)nullptr, (T*)nullptr);                           // :1353
+  T cb[STAGEC ? NMAX + 5 : 1];
+  T obuf[STAGEC ? 2 * (NMAX + OFF) * (NMAX + OFF) : 1];
+  rnea_config<FB, T, NMAX>(m, n, q + b * nv, qd + b * nv, qdd ? qdd + b * nv : nullptr, grav, st,
+                           c ? (STAGE ? cb : c + b * nv) : nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr);   // :1353
   T dvq[NMAX][6], daq[NMAX][6], dfq[NMAX][6], dvd[NMAX][6], dad[NMAX][6], dfd[NMAX][6];
-  T* row = dc + b * 2 * nv * nv;
+  T* row = STAGE ? obuf : dc + b * 2 * nv * nv;
   for (int col = 0; col < nv; ++col) {
     const int c0 = FB ? (col < 6 ? 0 : col - 5) : col;      // the body that owns the column
     // ---- forward recursions of the column over subtree(c0) ----
@@ -417,6 +465,11 @@ __global__ void __launch_bounds__(64) g_rnea_grad_kernel(const DevModel<T>* __re
       row[(i + OFF) * 2 * nv + nv + col] = ed;
     }
   }
+  if (STAGE) {
+    __shared__ T tile[64 * KCHP];
+    if (c) flush_coalesced([&](int k) { return cb[k]; }, nv, c + b0 * nv, nv, nvalid, tile, lane);
+    flush_coalesced([&](int k) { return obuf[k]; }, 2 * nv * nv, dc + b0 * 2 * nv * nv, 2LL * nv * nv, nvalid, tile, lane);
+  }
 }
 
 
@@ -461,10 +514,13 @@ template <class T, int NMAX>
 __global__ void __launch_bounds__(64) g_rnea_grad_world_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q,
                                                                const T* __restrict__ qd, const T* __restrict__ qdd, T grav,
                                                                int use_damping, long long B, T* __restrict__ c_out,
-                                                               T* __restrict__ dc) {
-  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+                                                               T* __restrict__ dc, int stage_rt) {
+  RBDG_LANE_CONFIG();
+  constexpr bool STAGEC = stage_outputs<NMAX>();
+  const bool STAGE = STAGEC && stage_rt;
   const int n = m->n;
+  T cb[STAGEC ? NMAX : 1];
+  T obuf[STAGEC ? 2 * NMAX * NMAX : 1];
   T Sv[NMAX][6], Pd[NMAX][6], Pdd[NMAX][6], vw[NMAX][6], aw[NMAX][6], Rw[NMAX][9], pw[NMAX][3];
   T Cm[NMAX][GCOMP];
   // ---- root -> leaves: world kinematics (:1413-1434) and every body's own inertia terms (:1436-1440) ----
@@ -592,7 +648,7 @@ __global__ void __launch_bounds__(64) g_rnea_grad_world_kernel(const DevModel<T>
     for (int r = 0; r < 6; ++r) { Cm[i][4 + r] = L.IC.I[r]; Cm[i][10 + r] = L.SC.TL[r]; Cm[i][19 + r] = L.pm[r]; Cm[i][25 + r] = L.f[r]; }
   }
   // ---- leaves -> root: composites (:1446-1448), c, t-vectors (:1481-1484), every (body, ancestor) pair ----
-  T* row = dc + b * 2 * n * n;
+  T* row = STAGE ? obuf : dc + b * 2 * n * n;
   for (int j = n - 1; j >= 0; --j) {
     GComp<T> C;
     C.IC.m = Cm[j][0];
@@ -608,7 +664,7 @@ __global__ void __launch_bounds__(64) g_rnea_grad_world_kernel(const DevModel<T>
     T S[6], psid[6], psidd[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) { S[r] = Sv[j][r]; psid[r] = Pd[j][r]; psidd[r] = Pdd[j][r]; }
-    if (c_out) c_out[b * n + j] = dot6g(S, C.f);
+    if (c_out) { const T cj = dot6g(S, C.f); if (STAGE) cb[j] = cj; else c_out[b * n + j] = cj; }
     T t1[6], t2[6], t3[6], t4[6];
     {
       T y3[6], s1[6], z1[6], zf[6], y2[6], s2[6], z2[6];
@@ -648,6 +704,11 @@ __global__ void __launch_bounds__(64) g_rnea_grad_world_kernel(const DevModel<T>
       }
     }
   }
+  if (STAGE) {
+    __shared__ T tile[64 * KCHP];
+    if (c_out) flush_coalesced([&](int k) { return cb[k]; }, n, c_out + b0 * n, n, nvalid, tile, lane);
+    flush_coalesced([&](int k) { return obuf[k]; }, 2 * n * n, dc + b0 * 2 * n * n, 2LL * n * n, nvalid, tile, lane);
+  }
 }
 
 // in-place inverse of a symmetric positive definite 6 x 6 (Gauss-Jordan, no pivoting needed)
@@ -670,11 +731,13 @@ GDEV void inv6_spd(T (&A)[36]) {
 
 template <class T, int NMAX, bool FB>
 __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, long long B,
-                                                    int dense, T* __restrict__ Minv) {
-  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
-  if (b >= B) return;
+                                                    int dense, T* __restrict__ Minv, int stage_rt) {
+  RBDG_LANE_CONFIG();
   constexpr int OFF = FB ? 5 : 0;
+  constexpr bool STAGEC = stage_outputs<NMAX>();
+  const bool STAGE = STAGEC && stage_rt;
   const int n = m->n, nv = n + OFF;
+  T obuf[STAGEC ? (NMAX + OFF) * (NMAX + OFF) : 1];
   T IA[NMAX][36];
   T U[NMAX][6], Di[NMAX], f1[NMAX], f2[NMAX];
   for (int i = 0; i < n; ++i) {
@@ -725,7 +788,7 @@ __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restric
         }
     }
   }
-  T* out = Minv + b * nv * nv;
+  T* out = STAGE ? obuf : Minv + b * nv * nv;
   T fbi[36];                                                 // floating base: inv(S^T IA_0 S) = inv(IA_0)   (:679-683)
   if (FB) {
 #pragma unroll
@@ -795,6 +858,10 @@ __global__ void __launch_bounds__(64) g_minv_kernel(const DevModel<T>* __restric
       if (i != c0) out[(c0 + OFF) * nv + i + OFF] = dense ? mm : T(0);      // (:799-804)
     }
   }
+  if (STAGE) {
+    __shared__ T tile[64 * KCHP];
+    flush_coalesced([&](int k) { return obuf[k]; }, nv * nv, Minv + b0 * nv * nv, (long long)nv * nv, nvalid, tile, lane);
+  }
 }
 
 // qdd = Minv (u - c)   (:1371-1374): one thread per (configuration, row)
@@ -829,6 +896,18 @@ __global__ void __launch_bounds__(256) g_neg_mm_kernel(int n, long long B, const
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 std::atomic<int> g_grad_kernel_option{0};
+std::atomic<int> g_stage_option{0};          // 0 auto, 1 never, 2 always (rbd_g_set_output_staging)
+// Staging the outputs (flush_coalesced) pays when the launch is throughput-bound: it trades partial-sector stores for a
+// serial epilogue per wave.  Measured (tools/time_generic.py, MI355X): 7-body arm at B = 1 M: rnea 1 486 -> 754 us,
+// minv 1 608 -> 1 139; 30-body humanoid at B = 16 384 (256 waves): rnea 138 -> 203 us, i.e. worse; at B = 65 536
+// (1 024 waves) staged wins again (576 -> 391 us; 7-body arm 80 -> 64 us).  AUTO: stage from one wave per SIMD upwards
+// (tools/time_generic_staging.py, profiles/r03_generic_staging_sweep.txt).
+inline int stage_for(long long B) {
+  const int o = g_stage_option.load(std::memory_order_relaxed);
+  if (o == 1) return 0;
+  if (o == 2) return 1;
+  return (B + 63) / 64 >= 1024 ? 1 : 0;
+}
 
 char* err_buf() {
   static thread_local char buf[512] = "";
@@ -951,7 +1030,7 @@ int rnea_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav,
   if (!q || !qd || !c) return fail(RBD_G_ERR_ARG, "rbd_g_rnea: q, qd, c must not be null");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f)
+#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f, stage_for(B))
   RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
@@ -968,14 +1047,14 @@ int grad_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav,
   const int opt = g_grad_kernel_option.load(std::memory_order_relaxed);
   if (m->world_ok && opt != RBD_G_GRAD_KERNEL_COLUMNS) {
     const int n_ = m->n;
-#define WCALL(NM) hipLaunchKernelGGL((g_rnea_grad_world_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
+#define WCALL(NM) hipLaunchKernelGGL((g_rnea_grad_world_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc, stage_for(B))
     if (n_ <= 8) { WCALL(8); } else if (n_ <= 16) { WCALL(16); } else if (n_ <= 32) { WCALL(32); } else { WCALL(64); }
 #undef WCALL
     hipError_t ew = hipGetLastError();
     return ew == hipSuccess ? 0 : hip_fail(ew, "rbd_g_rnea_grad (world-frame kernel) launch");
   }
   if (opt == RBD_G_GRAD_KERNEL_WORLD) return fail(RBD_G_ERR_UNSUPPORTED, "rbd_g_rnea_grad: the world-frame kernel needs a fixed base, revolute joints and rigid-body inertias");
-#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc)
+#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc, stage_for(B))
   RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
@@ -987,7 +1066,7 @@ int minv_host(const rbd_model* m, const T* q, long long B, int dense, T* Minv, v
   if (!q || !Minv) return fail(RBD_G_ERR_ARG, "rbd_g_minv: q, Minv must not be null");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM, FB) hipLaunchKernelGGL((g_minv_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv)
+#define CALL(NM, FB) hipLaunchKernelGGL((g_minv_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv, stage_for(B))
   RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
@@ -1112,6 +1191,11 @@ int rbd_model_nv(const rbd_model* m) { return m ? m->nv : 0; }
 int rbd_g_set_grad_kernel(int which) {
   if (which < 0 || which > 2) return rbdg::fail(RBD_G_ERR_ARG, "rbd_g_set_grad_kernel: %d", which);
   rbdg::g_grad_kernel_option.store(which, std::memory_order_relaxed);
+  return 0;
+}
+int rbd_g_set_output_staging(int which) {
+  if (which < 0 || which > 2) return rbdg::fail(RBD_G_ERR_ARG, "rbd_g_set_output_staging: %d", which);
+  rbdg::g_stage_option.store(which, std::memory_order_relaxed);
   return 0;
 }
 int rbd_g_grad_kernel_of(const rbd_model* m) {

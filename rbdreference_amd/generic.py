@@ -23,7 +23,7 @@ RBD_G_GRAD_KERNEL_AUTO, RBD_G_GRAD_KERNEL_COLUMNS, RBD_G_GRAD_KERNEL_WORLD = 0, 
 # every symbol include/rbd_generic.h declares (tests check the built library exports all of them)
 GENERIC_EXPORTED_SYMBOLS = [
     "rbd_g_abi_version", "rbd_g_last_error", "rbd_model_create", "rbd_model_destroy", "rbd_model_n", "rbd_model_nv",
-    "rbd_g_set_grad_kernel", "rbd_g_grad_kernel_of",
+    "rbd_g_set_grad_kernel", "rbd_g_grad_kernel_of", "rbd_g_set_output_staging",
     "rbd_g_rnea_f32", "rbd_g_rnea_f64", "rbd_g_rnea_grad_f32", "rbd_g_rnea_grad_f64",
     "rbd_g_minv_f32", "rbd_g_minv_f64", "rbd_g_fd_workspace_bytes",
     "rbd_g_forward_dynamics_f32", "rbd_g_forward_dynamics_f64",
@@ -54,6 +54,8 @@ def _declare(lib):
     lib.rbd_model_nv.argtypes = [c_void_p]
     lib.rbd_g_set_grad_kernel.restype = c_int
     lib.rbd_g_set_grad_kernel.argtypes = [c_int]
+    lib.rbd_g_set_output_staging.restype = c_int
+    lib.rbd_g_set_output_staging.argtypes = [c_int]
     lib.rbd_g_grad_kernel_of.restype = c_int
     lib.rbd_g_grad_kernel_of.argtypes = [c_void_p]
     lib.rbd_g_fd_workspace_bytes.restype = c_size_t
@@ -86,6 +88,8 @@ def load_generic_library(build: bool = True):
     with _LIB_LOCK:
         if _LIB is None:
             import os
+            import torch  # noqa: F401  -- FIRST: torch ships its own libamdhip64; loading this library before it would pull
+            #               a second HIP runtime into the process (hipErrorNoDevice from whichever initialises later)
             from .build import build_generic, generic_lib_path
             path = build_generic() if build else generic_lib_path()
             if not os.path.exists(path):

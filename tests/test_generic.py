@@ -22,6 +22,18 @@ def generic_for(name):
     return _G[name]
 
 
+@pytest.fixture(params=["direct", "staged"], autouse=True)
+def staging(request):
+    """Every test of this file runs with both ways results leave the kernels (rbd_g_set_output_staging): 4-byte
+    stores as the values are formed, and staged through private memory + an LDS tile (what AUTO uses for large
+    batches; forced here because the fixtures are small)."""
+    from rbdreference_amd.generic import load_generic_library
+    lib = load_generic_library()
+    assert lib.rbd_g_set_output_staging(2 if request.param == "staged" else 1) == 0
+    yield request.param
+    lib.rbd_g_set_output_staging(0)
+
+
 @pytest.fixture(params=["float32", "float64"])
 def prec(request):
     torch = _torch()
