@@ -223,9 +223,16 @@ class RbdLibrary:
         return self._generic
 
     def wait_specialized(self):
-        """Block until the robot's own full library is loaded (no-op in mode 'only'); returns self."""
-        if self._generic_mode != "only":
-            self.lib
+        """Block until the robot's own full library is loaded; returns self.  No-op in mode 'only', and where the
+        background build failed (no compiler on this machine) while the model-handle library serves the robot: every
+        call then stays on that one library, which is all `ShardedRBD` needs (no mixing of kernels between ranks)."""
+        if self._generic_mode == "only":
+            return self
+        if self._bg is not None:
+            self._bg.join()
+        if self._full is None and self._bg_err is not None and self._generic_serving() is not None:
+            return self
+        self.lib
         return self
 
     def serving(self, base: str, sfx: str, has_qdd: bool = True):

@@ -323,3 +323,23 @@ def test_generic_library_loads_exports_its_header_and_serves_a_never_built_robot
     assert only.served_by_generic() and only.get_option(0) == 0
     with pytest.raises(Exception, match="not served by the model-handle library"):
         only.fn("rbd_aba", "f32")
+
+
+def test_a_machine_without_hipcc_keeps_serving_from_the_model_handle_library(monkeypatch):
+    """No compiler (RBD_HIPCC points nowhere) and a robot that was never built: the background build fails, the
+    model-handle library (prebuilt, needs no compiler) keeps answering what it serves, `wait_specialized` returns
+    instead of raising (ShardedRBD can run), and an entry point it does not have reports the build error."""
+    from rbdreference_amd._lib import RbdLibrary
+    from rbdreference_amd.build import build_generic, full_library_ready
+    build_generic()                                   # shipped prebuilt in this scenario
+    monkeypatch.setenv("RBD_HIPCC", "/nonexistent/hipcc")
+    m = _fresh_robot("no_compiler_probe_n3", [-1, 0, 1], 4245)
+    assert not full_library_ready(m)
+    L = RbdLibrary(m, build=True, lazy=True, generic="auto")
+    L.fn("rbd_rnea_grad", "f32")
+    assert L.served_by_generic()
+    assert L.wait_specialized() is L and L._bg_err is not None
+    L.fn("rbd_minv", "f64")
+    assert L.served_by_generic()
+    with pytest.raises(RuntimeError, match="hipcc not found"):
+        L.fn("rbd_crba", "f32")
