@@ -149,6 +149,7 @@ class GenericModel:
                 setattr(self, f"rbd_{base}_{sfx}", self._bind(f"rbd_g_{base}_{sfx}"))
             setattr(self, f"rbd_minv_{sfx}", self._bind_minv(sfx))
             setattr(self, f"rbd_rnea_with_grad_{sfx}", self._bind_with_grad(sfx))
+            setattr(self, f"rbd_aba_{sfx}", self._bind_aba(sfx))
 
     # ---- handles ----------------------------------------------------------------------------------------------------
     def handle(self, device: int | None = None):
@@ -204,6 +205,22 @@ class GenericModel:
             return rc if rc != 0 else grad(h, q, qd, qdd, g, damp, B, None, dc, stream)
         return call
 
+    def _bind_aba(self, sfx):
+        """rbd_aba (RBDReference.py:940-1024: defined against forward_dynamics, as for the per-robot libraries): the
+        model-handle library has no articulated-body kernel, it evaluates Minv (tau - c) and owns the scratch here."""
+        fd = getattr(self.lib, f"rbd_g_forward_dynamics_{sfx}")
+        esz = 4 if sfx == "f32" else 8
+
+        def call(q, qd, tau, g, B, qdd, stream):
+            import torch
+            h = self.handle()
+            wsb = int(self.lib.rbd_g_fd_workspace_bytes(h, B, esz, 0))
+            ws = torch.empty((max(wsb, 1),), dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+            rc = fd(h, q, qd, tau, g, B, qdd, ws.data_ptr(), wsb, stream)
+            ws.record_stream(torch.cuda.current_stream())       # (the launches are asynchronous: the block outlives them)
+            return rc
+        return call
+
     def rbd_minv_workspace_bytes(self, B, esz):
         return 0
 
@@ -214,6 +231,8 @@ class GenericModel:
         return self.lib.rbd_g_last_error()
 
     def serves(self, base: str) -> bool:
+        if base == "rbd_aba":
+            return not self.model.floating       # (the reference's own aba raises for a floating base, :900)
         return base in self.SERVES
 
     def kernel_name(self, op: int, elem_size: int) -> str:

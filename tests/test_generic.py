@@ -99,6 +99,8 @@ def test_generic_minv_and_forward_dynamics_vs_golden(name, prec):
         check_conditioned("fd_dqd", b.contiguous(), g["fd_dqd"], g["H"])
     else:
         check("fd_qdd", rbd.forward_dynamics(q, qd, u), g["fd_qdd"], 1e-9)
+        check("aba_qdd", rbd.aba(q, qd, u), g["aba_qdd"], 1e-9)
+        assert rbd._lib.served_by_generic()
         a, b = rbd.forward_dynamics_grad(q, qd, u)
         check("fd_dq", a.contiguous(), g["fd_dq"], 1e-9); check("fd_dqd", b.contiguous(), g["fd_dqd"], 1e-9)
 

@@ -321,8 +321,10 @@ def test_generic_library_loads_exports_its_header_and_serves_a_never_built_robot
     only = RbdLibrary(m, build=True, generic="only")
     only.fn("rbd_minv", "f64")
     assert only.served_by_generic() and only.get_option(0) == 0
+    only.fn("rbd_aba", "f32")                              # Minv (tau - c) through rbd_g_forward_dynamics
+    assert only.served_by_generic()
     with pytest.raises(Exception, match="not served by the model-handle library"):
-        only.fn("rbd_aba", "f32")
+        only.fn("rbd_crba", "f32")
 
 
 def test_a_machine_without_hipcc_keeps_serving_from_the_model_handle_library(monkeypatch):
