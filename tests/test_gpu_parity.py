@@ -796,3 +796,43 @@ def test_iiwa_auto_path_at_configs1_and_at_the_selection_boundary(B):
                           ("dc_du (one call)", dc2, dcr)):
         e = rel_err_rows(got[rows].double().cpu().numpy(), want)
         assert e <= 1e-5, (nm, e)
+
+
+def test_bound_launches_equal_the_methods_and_replay_in_a_graph():
+    """RBDReference.bind: one ctypes call per launch on pre-allocated buffers -- bit-identical to the methods, reads
+    the caller's buffers in place (new inputs, same launch), capturable in a torch.cuda.graph; the per-call cost is
+    printed next to the method's (configs[1]'s shape: the 7-DoF arm at B = 4096)."""
+    import time
+    torch = _torch()
+    rbd = rbd_for("iiwa_like")
+    B = 4096
+    rng = np.random.default_rng(12)
+    q, qd, qdd = dev_tensors(torch.float32, rng.uniform(-3, 3, (B, 7)), rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, 7)))
+    for op, ref in (("rnea", lambda: rbd.rnea(q, qd, qdd)), ("rnea_grad", lambda: rbd.rnea_grad(q, qd, qdd, return_c=True)),
+                    ("rnea_and_grad", lambda: rbd.rnea_and_grad(q, qd, qdd)), ("minv", lambda: (rbd.minv(q),))):
+        launch = rbd.bind(op, q, qd, qdd) if op != "minv" else rbd.bind(op, q)
+        outs = launch()
+        for a, b in zip(outs, ref()):
+            assert torch.equal(a, b), op
+    launch = rbd.bind("rnea_and_grad", q, qd, qdd)
+    q2 = torch.tensor(rng.uniform(-3, 3, (B, 7)), device="cuda:0", dtype=torch.float32)
+    want = rbd.rnea_and_grad(q2, qd, qdd)
+    q.copy_(q2)                                           # the launch reads the caller's buffer in place
+    for a, b in zip(launch(), want):
+        assert torch.equal(a, b)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        launch(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            launch()
+    launch.outputs[4].zero_(); g.replay(); torch.cuda.synchronize()
+    assert torch.equal(launch.outputs[4], want[4])
+    with pytest.raises(ValueError):
+        rbd.bind("rnea", q[::2], qd[::2], qdd[::2])         # not contiguous: the launch could not read it in place
+    for nm, fn in (("method", lambda: rbd.rnea_and_grad(q, qd, qdd)), ("bound", launch)):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(300):
+            fn()
+        torch.cuda.synchronize()
+        print(f"\nrnea_and_grad B={B}: {nm} {(time.perf_counter() - t0) / 300 * 1e6:.1f} us per call", end="")
