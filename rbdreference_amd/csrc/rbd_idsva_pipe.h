@@ -198,13 +198,12 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
       });
       a[5] -= grav;
     } else {
-      T t1[6], t2[6];
+      T t1[6];
       crm6(v, Sv[j], Pd[j]);                               // psid  = v_p x S                 (:1431)
       crm6(a, Sv[j], t1);                                  // psidd = a_p x S + v_p x psid    (:1432)
-      crm6(v, Pd[j], t2);
+      crm6_add(v, Pd[j], t1, Pdd[j]);
       sfor<0, 6>([&](auto R_) {
         constexpr int r = decltype(R_)::value;
-        Pdd[j][r] = t1[r] + t2[r];
         v[r] = fma_(Sv[j][r], qdv[j], v[r]);                                   // (:1433)
         a[r] = fma_(Sv[j][r], qddv[j], fma_(Pd[j][r], qdv[j], a[r]));         // (:1430,:1434)
       });
@@ -282,85 +281,82 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
         sfor<0, 6>([&](auto E_) {
           constexpr int e = decltype(E_)::value, r = IR[e], c = IC_[e];
           T s = fma_(A[r][0], Rm[c][0], fma_(A[r][1], Rm[c][1], A[r][2] * Rm[c][2]));
-          const T mcc = L.h[r] * cw[c];                      // m cw_r cw_c
-          if constexpr (r == c) s += fma_(L.m, cc, -mcc); else s -= mcc;
+          s = fma_(-L.h[r], cw[c], s);                       // - m cw_r cw_c
+          if constexpr (r == c) s = fma_(L.m, cc, s);
           L.I[e] = s;
         });
       }
-      T pm[6], fl[6], Ia[6];
-      rin_apply(L, v, pm);                                    // momentum I v
-      rin_apply(L, a, Ia);
-      fxv<false>(v, pm, fl);                                  // f = I a + v x* (I v)   (:1440)
-      sfor<0, 6>([&](auto R_) { fl[decltype(R_)::value] += Ia[decltype(R_)::value]; });
-      // Sym part of B = crf(v) I + icrf(I v) - I crm(v):  TL = K + K^T - (h u^T + u h^T) + 2 (u.h) 1,
-      // K = w^x Ibar ;  G = w x h + m u
-      SymB<T> Sl;
+      // momentum I v, force f = I a + v x* (I v) (:1440), Sym part of B = crf(v) I + icrf(I v) - I crm(v):
+      //   TL = K + K^T - (h u^T + u h^T) + 2 (u.h) 1,  K = w^x Ibar ;  G = w x h + m u
+      // -- every one of them joins its composite (plain sums in the world frame, :1446-1448) as the START of its own
+      // FMA chain instead of through a separate add (rbd_world.h, "accumulate forms")
+      T pm[6];
+      rin_apply(L, v, pm);
+      if constexpr (j == last) {
+        T Ia[6];
+        rin_apply(L, a, Ia);
+        fxv_add(v, pm, Ia, fC);
+        IC = L;
+        sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; pmC[r] = pm[r]; });
+      } else {
+        T t[6];
+        rin_apply_acc(L, a, fC, t);
+        fxv_add(v, pm, t, fC);
+        IC.m += L.m;
+        sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; IC.h[r] += L.h[r]; });
+        sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; IC.I[r] += L.I[r]; pmC[r] += pm[r]; });
+      }
       {
         const T w[3] = {v[0], v[1], v[2]}, u[3] = {v[3], v[4], v[5]};
         const T Ifull[3][3] = {{L.I[0], L.I[1], L.I[2]}, {L.I[1], L.I[3], L.I[4]}, {L.I[2], L.I[4], L.I[5]}};
-        T K[3][3];
-        sfor<0, 3>([&](auto C_) {
-          constexpr int c = decltype(C_)::value;
-          const T col[3] = {Ifull[0][c], Ifull[1][c], Ifull[2][c]};
-          T o[3];
-          cross3(w, col, o);
-          K[0][c] = o[0]; K[1][c] = o[1]; K[2][c] = o[2];
-        });
-        const T uh2 = T(2) * fma_(u[0], L.h[0], fma_(u[1], L.h[1], u[2] * L.h[2]));
+        const T uh = fma_(u[0], L.h[0], fma_(u[1], L.h[1], u[2] * L.h[2]));
         constexpr int IR[6] = {0, 0, 0, 1, 1, 2}, IC_[6] = {0, 1, 2, 1, 2, 2};
         sfor<0, 6>([&](auto E_) {
           constexpr int e = decltype(E_)::value, r = IR[e], c = IC_[e];
-          T s = K[r][c] + K[c][r];
-          s = fma_(-L.h[r], u[c], fma_(-u[r], L.h[c], s));
-          if constexpr (r == c) s += uh2;
-          Sl.TL[e] = s;
+          constexpr int r1 = (r + 1) % 3, r2 = (r + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+          const T base = (j == last) ? T(0) : SC.TL[e];
+          if constexpr (r == c) {       // 2 K_rr - 2 h_r u_r + 2 (u.h)
+            const T d = fma_(-L.h[r], u[r], fma_(w[r1], Ifull[r2][r], fma_(-w[r2], Ifull[r1][r], uh)));
+            SC.TL[e] = fma_(T(2), d, base);
+          } else {                      // K_rc + K_cr - h_r u_c - u_r h_c
+            T x = fma_(w[r1], Ifull[r2][c], fma_(-w[r2], Ifull[r1][c], base));
+            x = fma_(w[c1], Ifull[c2][r], fma_(-w[c2], Ifull[c1][r], x));
+            SC.TL[e] = fma_(-L.h[r], u[c], fma_(-u[r], L.h[c], x));
+          }
         });
-        T g[3];
-        cross3(w, L.h, g);
-        sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; Sl.G[r] = fma_(L.m, u[r], g[r]); });
-      }
-      // composites (plain sums in the world frame, :1446-1448)
-      if constexpr (j == last) {
-        IC = L; SC = Sl;
-        sfor<0, 6>([&](auto R_) { constexpr int r = decltype(R_)::value; pmC[r] = pm[r]; fC[r] = fl[r]; });
-      } else {
-        IC.m += L.m;
-        sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; IC.h[r] += L.h[r]; SC.G[r] += Sl.G[r]; });
-        sfor<0, 6>([&](auto R_) {
-          constexpr int r = decltype(R_)::value;
-          IC.I[r] += L.I[r]; SC.TL[r] += Sl.TL[r]; pmC[r] += pm[r]; fC[r] += fl[r];
+        sfor<0, 3>([&](auto R_) {
+          constexpr int r = decltype(R_)::value, r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+          const T base = (j == last) ? T(0) : SC.G[r];
+          SC.G[r] = fma_(L.m, u[r], fma_(w[r1], L.h[r2], fma_(-w[r2], L.h[r1], base)));
         });
       }
       // c_j and the t-vectors (:1481-1484)
       cv[j] = dot6(Sv[j], fC);
       if constexpr (j > rs && (IDS_PIPE_C_PARK && ids_c_parks(row0, rows, ra))) my[ids_c_slot(row0, rows, ra, j - rs - 1)] = cv[j];
-      T y1[6], y3[6], s1[6], z1[6], zf[6];
-      rin_apply(IC, Sv[j], y1);
-      rin_apply(IC, Pdd[j], y3);
-      sym_apply(SC, Sv[j], s1);
-      fxv<false>(Sv[j], pmC, z1);
-      fxv<false>(Sv[j], fC, zf);
       T t1[6], t2[6], t3[6], t4[6];
-      if constexpr (PARENT[j] < 0) {
-        sfor<0, 6>([&](auto R_) {
-          constexpr int r = decltype(R_)::value;
-          t1[r] = y1[r];
-          t4[r] = s1[r] - z1[r];
-          t3[r] = y3[r] + zf[r];
-          t2[r] = s1[r] + z1[r];
-        });
-      } else {
-        T y2[6], s2[6], z2[6];
-        rin_apply(IC, Pd[j], y2);
-        sym_apply(SC, Pd[j], s2);
-        fxv<false>(Pd[j], pmC, z2);
-        sfor<0, 6>([&](auto R_) {
-          constexpr int r = decltype(R_)::value;
-          t1[r] = y1[r];
-          t4[r] = s1[r] - z1[r];
-          t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
-          t2[r] = fma_(T(2), y2[r], s1[r] + z1[r]);
-        });
+      {
+        T y3[6], s1[6], yf[6];
+        rin_apply(IC, Sv[j], t1);                             // t1 = IC S
+        sym_apply(SC, Sv[j], s1);
+        fxv_sub(Sv[j], pmC, s1, t4);                          // t4 = SC S - S x* pmC
+        rin_apply(IC, Pdd[j], y3);
+        fxv_add(Sv[j], fC, y3, yf);                           // IC psidd + S x* fC
+        if constexpr (PARENT[j] < 0) {                        // psid of a root is identically zero
+          sfor<0, 6>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            t3[r] = yf[r];
+            t2[r] = fma_(T(2), s1[r], -t4[r]);                // SC S + S x* pmC = 2 SC S - t4
+          });
+        } else {
+          T y2[6], ys[6];
+          rin_apply(IC, Pd[j], y2);
+          sym_apply_acc(SC, Pd[j], yf, ys);                   // + SC psid
+          fxv_add(Pd[j], pmC, ys, t3);                        // + psid x* pmC
+          sfor<0, 6>([&](auto R_) {
+            constexpr int r = decltype(R_)::value;
+            t2[r] = fma_(T(2), y2[r] + s1[r], -t4[r]);        // 2 IC psid + SC S + S x* pmC
+          });
+        }
       }
       // all pairs (j, jj) with jj an ancestor-or-self of j
       sfor<row0, j + 1>([&](auto JJ) {
@@ -370,7 +366,7 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
           dq_ij = fma_(t1[3], Pdd[jj][3], t1[4] * Pdd[jj][4]);
           dqd_ij = dot6(t4, Sv[jj]);
         } else {
-          dq_ij = dot6(t4, Pd[jj]) + dot6(t1, Pdd[jj]);
+          dq_ij = dot6_acc(t1, Pdd[jj], dot6(t4, Pd[jj]));
           dqd_ij = fma_(T(2), dot6(t1, Pd[jj]), dot6(t4, Sv[jj]));
         }
         if constexpr (jj == j) dqd_ij += sel(use_damping != 0, T(DAMPING[j]), T(0));   // :1336-1341

@@ -69,6 +69,74 @@ RBD_DEV void sym_apply(const SymB<T>& S, const T (&x)[6], T (&y)[6]) {
   y[3] = -ga[0]; y[4] = -ga[1]; y[5] = -ga[2];
 }
 
+// ---- accumulate forms (rbd_idsva_pipe.h) -----------------------------------------------------------------
+// "X = A + (a product chain)" costs a multiply to start the chain and an add to join it; started FROM A the chain is
+// FMAs only: one instruction less per component.  The one-lane chain kernel is bound by VALU issue (DESIGN.md
+// §3.1 a'), so the ~55 joins per body of the backward sweep are worth folding.  Same values up to rounding order.
+template <class T>
+RBD_DEV T dot6_acc(const T (&x)[6], const T (&y)[6], T acc) {
+  return fma_(x[5], y[5], fma_(x[4], y[4], fma_(x[3], y[3], fma_(x[2], y[2], fma_(x[1], y[1], fma_(x[0], y[0], acc))))));
+}
+// r = acc + crf(v) b   (fxv, rbd_spatial.h)
+template <class T>
+RBD_DEV void fxv_add(const T (&v)[6], const T (&b)[6], const T (&acc)[6], T (&r)[6]) {
+  const T r0 = fma_(v[1], b[2], fma_(-v[2], b[1], fma_(v[4], b[5], fma_(-v[5], b[4], acc[0]))));
+  const T r1 = fma_(v[2], b[0], fma_(-v[0], b[2], fma_(v[5], b[3], fma_(-v[3], b[5], acc[1]))));
+  const T r2 = fma_(v[0], b[1], fma_(-v[1], b[0], fma_(v[3], b[4], fma_(-v[4], b[3], acc[2]))));
+  const T r3 = fma_(v[1], b[5], fma_(-v[2], b[4], acc[3]));
+  const T r4 = fma_(v[2], b[3], fma_(-v[0], b[5], acc[4]));
+  const T r5 = fma_(v[0], b[4], fma_(-v[1], b[3], acc[5]));
+  r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4; r[5] = r5;
+}
+// r = acc - crf(v) b
+template <class T>
+RBD_DEV void fxv_sub(const T (&v)[6], const T (&b)[6], const T (&acc)[6], T (&r)[6]) {
+  const T r0 = fma_(-v[1], b[2], fma_(v[2], b[1], fma_(-v[4], b[5], fma_(v[5], b[4], acc[0]))));
+  const T r1 = fma_(-v[2], b[0], fma_(v[0], b[2], fma_(-v[5], b[3], fma_(v[3], b[5], acc[1]))));
+  const T r2 = fma_(-v[0], b[1], fma_(v[1], b[0], fma_(-v[3], b[4], fma_(v[4], b[3], acc[2]))));
+  const T r3 = fma_(-v[1], b[5], fma_(v[2], b[4], acc[3]));
+  const T r4 = fma_(-v[2], b[3], fma_(v[0], b[5], acc[4]));
+  const T r5 = fma_(-v[0], b[4], fma_(v[1], b[3], acc[5]));
+  r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3; r[4] = r4; r[5] = r5;
+}
+// o = acc + crm(v) x
+template <class T>
+RBD_DEV void crm6_add(const T (&v)[6], const T (&x)[6], const T (&acc)[6], T (&o)[6]) {
+  const T w[3] = {v[0], v[1], v[2]}, u[3] = {v[3], v[4], v[5]};
+  const T xa[3] = {x[0], x[1], x[2]}, xb[3] = {x[3], x[4], x[5]};
+  T oa[3] = {acc[0], acc[1], acc[2]}, ob[3] = {acc[3], acc[4], acc[5]};
+  cross3_acc(w, xa, oa);
+  cross3_acc(u, xa, ob);
+  cross3_acc(w, xb, ob);
+  o[0] = oa[0]; o[1] = oa[1]; o[2] = oa[2]; o[3] = ob[0]; o[4] = ob[1]; o[5] = ob[2];
+}
+// y = acc + R x   (rin_apply)
+template <class T>
+RBD_DEV void rin_apply_acc(const RInertia<T>& R, const T (&x)[6], const T (&acc)[6], T (&y)[6]) {
+  const T w[3] = {x[0], x[1], x[2]}, u[3] = {x[3], x[4], x[5]};
+  T top[3] = {fma_(R.I[0], w[0], fma_(R.I[1], w[1], fma_(R.I[2], w[2], acc[0]))),
+              fma_(R.I[1], w[0], fma_(R.I[3], w[1], fma_(R.I[4], w[2], acc[1]))),
+              fma_(R.I[2], w[0], fma_(R.I[4], w[1], fma_(R.I[5], w[2], acc[2])))};
+  cross3_acc(R.h, u, top);
+  y[0] = top[0]; y[1] = top[1]; y[2] = top[2];
+  // bottom: m u - h x w  =  m u + w x h
+  T bot[3] = {fma_(R.m, u[0], acc[3]), fma_(R.m, u[1], acc[4]), fma_(R.m, u[2], acc[5])};
+  cross3_acc(w, R.h, bot);
+  y[3] = bot[0]; y[4] = bot[1]; y[5] = bot[2];
+}
+// y = acc + Sym x   (sym_apply): [TL a + G x b ; -G x a] = [.. ; a x G]
+template <class T>
+RBD_DEV void sym_apply_acc(const SymB<T>& S, const T (&x)[6], const T (&acc)[6], T (&y)[6]) {
+  const T a[3] = {x[0], x[1], x[2]}, b[3] = {x[3], x[4], x[5]};
+  T top[3] = {fma_(S.TL[0], a[0], fma_(S.TL[1], a[1], fma_(S.TL[2], a[2], acc[0]))),
+              fma_(S.TL[1], a[0], fma_(S.TL[3], a[1], fma_(S.TL[4], a[2], acc[1]))),
+              fma_(S.TL[2], a[0], fma_(S.TL[4], a[1], fma_(S.TL[5], a[2], acc[2])))};
+  cross3_acc(S.G, b, top);
+  T bot[3] = {acc[3], acc[4], acc[5]};
+  cross3_acc(a, S.G, bot);
+  y[0] = top[0]; y[1] = top[1]; y[2] = top[2]; y[3] = bot[0]; y[4] = bot[1]; y[5] = bot[2];
+}
+
 // ---- compile-time chain decomposition (tables, so that constexpr evaluation stays O(n^2)) ---------
 struct TreePlan {
   int sub[N > 0 ? N : 1] = {};       // subtree size
