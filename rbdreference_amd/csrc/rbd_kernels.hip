@@ -1263,6 +1263,10 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
 #include "rbd_idsva.h"
 #include "rbd_idsva_pipe.h"
 #include "rbd_idsva_tree.h"
+#if defined(RBD_TU_GRAD_F64) || defined(RBD_TU_GRADN_F64)
+#include "rbd_idsva_tree_ws.h"   // fp64 only: the fp32 units never see it (their cached objects stay valid when it changes)
+#define RBD_HAVE_TWS 1
+#endif
 #ifdef RBD_NEED_GRAD
 #include "rbd_grad_cols.h"
 #endif
@@ -2059,6 +2063,41 @@ int resident_blocks(K kernel, int threads, size_t lds, int* out) {
   *out = n;
   return 0;
 }
+}  // namespace
+
+// Library-owned scratch of the workspace gradient kernel (rbd_idsva_tree_ws.h): one buffer per (device, stream),
+// grown on demand and kept.  Launches on one stream are ordered and share it; launches on different streams get
+// different buffers.  The first call on a stream allocates (hipMalloc is not capturable: run a call once before
+// capturing it into a graph, as for every kernel that needs hipFuncSetAttribute).  One pool, owned by the COMMON unit.
+extern "C" __attribute__((visibility("hidden"))) int rbd_stream_workspace(void* stream, size_t bytes, void** out);
+#ifdef RBD_TU_COMMON
+extern "C" int rbd_stream_workspace(void* stream, size_t bytes, void** out) {
+  struct Buf { void* p = nullptr; size_t n = 0; };
+  static std::mutex mu;
+  static std::unordered_map<const void*, Buf> pool[RBD_MAX_DEVICES];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const int slot = dev >= 0 && dev < RBD_MAX_DEVICES ? dev : 0;
+  std::lock_guard<std::mutex> g(mu);
+  Buf& b = pool[slot][stream];
+  if (b.n < bytes) {
+    if (b.p) {   // hipFree waits for the device: the launches that used the old buffer are over
+      hipError_t e = hipFree(b.p);
+      b = Buf{};
+      if (e != hipSuccess) return hip_fail(e, "rbd workspace hipFree");
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(e, "rbd workspace hipMalloc");
+    b.p = p;
+    b.n = bytes;
+  }
+  *out = b.p;
+  return 0;
+}
+#endif
+
+namespace {
 
 #ifdef RBD_NEED_RNEA
 template <class T>
@@ -2276,6 +2315,63 @@ int grad_cols_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_d
   }
 }
 
+// fp64 trees on the workspace kernel (rbd_idsva_tree_ws.h).  Default where the fp32 default is the tree kernel
+// (Atlas: the two-lane column kernel spilled 388 registers there and is no longer built in fp64); with
+// RBD_OPT_GRAD_KERNEL = TREE for every other fp64 robot whose root path does not fit the register plan.
+#ifndef RBD_HAVE_TWS
+template <class T>
+constexpr bool tws_built() { return false; }
+template <class T>
+constexpr bool tws_only() { return false; }
+template <class T, bool HAS_QDD>
+int tree_ws_launch(const T*, const T*, const T*, T, int, int64_t, T*, T*, void*) {
+  return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: the workspace tree kernel is not part of this unit");
+}
+#else
+template <class T>
+constexpr bool tws_built() {
+  using namespace rbdk;
+  constexpr bool reg_plan = N <= 12 && rbdm::MAXDEPTH <= 5;   // served by rnea_grad_tree_kernel<double>
+  if constexpr (!tws_ok<T>() || reg_plan) return false;
+  else return GRAD_TREE_DEFAULT || !RBD_FAST_STAGE;
+}
+template <class T>
+constexpr bool tws_only() { return tws_built<T>() && rbdk::GRAD_TREE_DEFAULT; }
+template <class T, bool HAS_QDD>
+int tree_ws_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* dc_du, void* stream) {
+  using namespace rbdk;
+  if constexpr (!tws_built<T>()) {
+    return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: the workspace tree kernel is not built for this robot");
+  } else {
+    constexpr size_t lds = tws_lds_bytes<T>();
+    auto k = rnea_grad_tree_ws_kernel<T, HAS_QDD>;
+    int rc, resident = 0;
+    if ((rc = ensure_lds(k, lds)) != 0) return rc;
+    if ((rc = resident_blocks(k, 64 * TWS_W, lds, &resident)) != 0) return rc;
+    const int yroots = TWS_MULTI ? 1 : tree_n_roots();
+    // one launch covers what is resident at once; larger batches walk the same workspace chunk by chunk
+    int64_t xblocks = resident / yroots;
+    if (xblocks < 1) xblocks = 1;
+    const int64_t need = (B + 63) / 64;
+    if (xblocks > need) xblocks = need;
+    const int64_t rows = xblocks * 64;
+    void* ws = nullptr;
+    if ((rc = rbd_stream_workspace(stream, (size_t)rows * TWS_SLOTS * sizeof(T), &ws)) != 0) return rc;
+    T* pws = reinterpret_cast<T*>(ws);
+    T* ews = pws + (size_t)64 * TWS_PATH_SLOTS;   // [block][slot][lane]: a block's entry slots follow its path slots
+    for (int64_t r0 = 0; r0 < B; r0 += rows) {
+      const int64_t nb = B - r0 < rows ? B - r0 : rows;
+      hipLaunchKernelGGL(k, dim3((unsigned)((nb + 63) / 64), yroots), dim3(64 * TWS_W), lds, (hipStream_t)stream, q + r0 * N, qd + r0 * N,
+                         qdd ? qdd + r0 * N : nullptr, gravity, use_damping, (long long)nb, c ? c + r0 * N : nullptr,
+                         dc_du + r0 * (2 * N * N), pws, ews);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad (workspace tree kernel) launch");
+    }
+    return 0;
+  }
+}
+#endif  // RBD_HAVE_TWS
+
 // One instantiation per (T, HAS_QDD): the forward-dynamics units only ever need HAS_QDD = true.
 template <class T, bool HAS_QDD>
 int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B,
@@ -2284,6 +2380,10 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
   if (grad_use_cols<T>(B)) return grad_cols_launch<T, HAS_QDD>(q, qd, qdd, gravity, use_damping, B, c, nullptr, nullptr, nullptr, dc_du, stream);
   // fp32 robots whose default is the tree kernel never build the column kernel (Atlas: 404 VGPRs of
   // code nobody runs); fp64 x big tree would need > 512 VGPRs and is not built either.
+  if constexpr (tws_built<T>()) {
+    if (tws_only<T>() || rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE)
+      return tree_ws_launch<T, HAS_QDD>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+  }
   constexpr bool TREE_ONLY = GRAD_TREE_DEFAULT && sizeof(T) == 4;
   constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || (N <= 12 && rbdm::MAXDEPTH <= 5));   // fp64: the root path's S / psid / psidd (36 registers per body) must fit 512 VGPRs without scratch
   if constexpr (TREE_BUILT) {
@@ -2302,8 +2402,8 @@ int rnea_grad_launch_q(const T* q, const T* qd, const T* qdd, T gravity, int use
       return 0;
     }
   }
-  if constexpr (TREE_ONLY) {
-    return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: no kernel");   // unreachable (static_assert above)
+  if constexpr (TREE_ONLY || tws_only<T>()) {
+    return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: no kernel");   // unreachable (static_assert / return above)
   } else if constexpr (grad_chain_kernel<T>()) {
     // one lane per configuration, tile-walking blocks (rbd_idsva.h)
     return idsva_launch<T, HAS_QDD, false>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream, nullptr);
@@ -2359,7 +2459,10 @@ int grad_kernel_name(int64_t B, char* buf, size_t len) {
   constexpr bool TREE_BUILT = RBD_FAST_STAGE ? TREE_ONLY : GRAD_TREE_OK && (sizeof(T) == 4 || (N <= 12 && rbdm::MAXDEPTH <= 5));   // fp64: the root path's S / psid / psidd (36 registers per body) must fit 512 VGPRs without scratch
   bool tree = TREE_ONLY;
   if constexpr (TREE_BUILT) tree = tree || (rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE && tree_lds_bytes<T>() <= 160 * 1024);
-  if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);
+  bool tws = false;
+  if constexpr (tws_built<T>()) tws = tws_only<T>() || rbd_option(RBD_OPT_GRAD_KERNEL) == RBD_GRAD_KERNEL_TREE;
+  if (tws) std::snprintf(buf, len, "rnea_grad_tree_ws_kernel<%s,true>", t);
+  else if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);
   else if (grad_chain_kernel<T>()) {
 #ifndef RBD_EXP_NO_PIPE
     if (IDS_PIPE_OK && sizeof(T) == 4) std::snprintf(buf, len, "rnea_grad_idsva_pipe_kernel<%s,true>", t);

@@ -664,6 +664,59 @@ def test_tree_gradient_kernel_forced_on_every_robot():
     assert ran_tree >= 8, ran_tree      # iiwa, quadruped, chain, tree in both precisions, Atlas in fp32, ...
 
 
+@pytest.mark.parametrize("name,forced", [("atlas_like", False), ("random_limbs_n14", False), ("iiwa_like", True),
+                                         ("random_chain_n7", True)])
+def test_fp64_workspace_tree_kernel(name, forced):
+    """fp64 rnea_grad of trees too big for registers + LDS (rbd_idsva_tree_ws.h): path vectors, pending entries and
+    parked composites in a library-owned global workspace.  Default for the robots whose fp32 default is the tree
+    kernel (Atlas, the 14-body limbs robot), on request for the chains.  Checked: the golden vectors of the real
+    reference (qdd given / None, damping), a ragged batch row by row, a batch that walks the workspace in several
+    chunks (rows on both sides of every chunk boundary are bit-identical to a small call and agree with the oracle),
+    and two streams at once (one workspace per stream)."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    from rbdreference_amd._lib import RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_TREE, RBD_OP_RNEA_GRAD, RBD_OPT_GRAD_KERNEL
+    g = load_golden(name); rbd = rbd_for(name); n = rbd.n
+    if forced:
+        rbd._lib.set_option(RBD_OPT_GRAD_KERNEL, RBD_GRAD_KERNEL_TREE)
+    try:
+        assert "rnea_grad_tree_ws_kernel<double" in rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 8, 16384)
+        q, qd, qdd = dev_tensors(torch.float64, g["q"], g["qd"], g["qdd"])
+        c, dc = rbd.rnea_grad(q, qd, qdd, return_c=True)
+        check("dc_du", dc, g["dc_du"], TOL64); check("c", c, g["c"], TOL64)
+        check("dc_du qdd=None", rbd.rnea_grad(q, qd), g["dc_du_noqdd"], TOL64)
+        check("dc_du damped", rbd.rnea_grad(q, qd, qdd, USE_VELOCITY_DAMPING=True), g["dc_du_damped"], TOL64)
+        rng = np.random.default_rng(11)
+        B = 3 * 16384 + 71          # at least three chunks on a 256-CU device (one 64-row block per CU and launch)
+        Q, QD, QDD = (rng.uniform(-3, 3, (B, n)), rng.uniform(-1, 1, (B, n)), rng.uniform(-1, 1, (B, n)))
+        tq, tqd, tqdd = dev_tensors(torch.float64, Q, QD, QDD)
+        cb, dcb = rbd.rnea_grad(tq, tqd, tqdd, return_c=True)
+        om = orc.model_from_robot(make_robot(name))
+        for lo in (0, 16384 - 70, 2 * 16384 - 70, 3 * 16384 - 70, B - 130):
+            hi = min(lo + 130, B)
+            c1, dc1 = rbd.rnea_grad(tq[lo:hi], tqd[lo:hi], tqdd[lo:hi], return_c=True)       # ragged: 130 or fewer rows
+            assert torch.equal(dc1, dcb[lo:hi]) and torch.equal(c1, cb[lo:hi]), (name, lo)
+            c_ref, dc_ref = orc.rnea_grad(om, Q[lo:hi], QD[lo:hi], QDD[lo:hi], return_c=True)
+            check("dc_du rows", dcb[lo:hi], dc_ref, TOL64); check("c rows", cb[lo:hi], c_ref, TOL64)
+        for b in (0, 63, 64, 129):
+            assert torch.equal(rbd.rnea_grad(tq[b], tqd[b], tqdd[b]), dcb[b]), (name, b)
+        # two streams, interleaved launches: every stream owns its workspace
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(3):
+            with torch.cuda.stream(s1):
+                outs.append(rbd.rnea_grad(tq[:20000], tqd[:20000], tqdd[:20000]))
+            with torch.cuda.stream(s2):
+                outs.append(rbd.rnea_grad(tq[20000:40000], tqd[20000:40000], tqdd[20000:40000]))
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            lo = 0 if k % 2 == 0 else 20000
+            assert torch.equal(o, dcb[lo:lo + 20000]), (name, "streams", k)
+    finally:
+        rbd._lib.set_option(RBD_OPT_GRAD_KERNEL, RBD_GRAD_KERNEL_AUTO)
+
+
 @pytest.mark.parametrize("name", ["atlas_like", "random_limbs_n14", "random_tree_n9", "random_forest_n8"])
 def test_minv_both_phase_a_kernels(name):
     """Robots too big for the one-lane minv kernel: phase A with one lane per configuration (the default from
