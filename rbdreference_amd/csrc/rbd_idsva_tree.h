@@ -61,6 +61,19 @@ constexpr bool tree_barrier_plan_ok() {
     if (TP.head[p] != r) return false;                 // ... on the root's heavy chain
     if (TP.wave_of[p] == TP.wave_of[sh]) return false; // and the side subtree runs on another wave
   }
+  // subtrees handed to another wave for load balance (TreePlan): consumed by the main wave after its barrier only
+  for (int x = 0; x < N; ++x) {
+    int rt = x;
+    while (PARENT[rt] >= 0) rt = PARENT[rt];
+    if (TP.on_side[x] || TP.wave_of[x] == TP.wave_of[rt]) continue;
+    int top = x;                                          // head of the handed-over subtree
+    while (PARENT[top] >= 0 && TP.wave_of[PARENT[top]] == TP.wave_of[x] && !(TP.head[PARENT[top]] == rt)) top = PARENT[top];
+    const int p = PARENT[top], sh = TP.side_head[TP.rootidx[rt]];
+    if (p < 0 || sh < 0 || TP.head[p] != rt || TP.wave_of[p] != TP.wave_of[rt]) return false;
+    bool above = false;
+    for (int y = PARENT[sh]; y >= 0; y = PARENT[y]) above = above || y == p;
+    if (!above) return false;
+  }
   return true;
 }
 static_assert(!TREE_MULTI || tree_barrier_plan_ok(), "multi-wave tree kernel: a wave would pass its block barrier zero or two times");

@@ -69,8 +69,11 @@ struct TwsRef {   // pw(slot) = x;  x = pw(slot);
   }
 };
 
+#ifndef RBD_TWS_MINBLOCKS                                      // experiments: blocks per CU the register budget must allow
+#define RBD_TWS_MINBLOCKS 1
+#endif
 template <class T, bool HAS_QDD>
-__global__ __launch_bounds__(64 * TWS_W, 1) void rnea_grad_tree_ws_kernel(const T* __restrict__ q, const T* __restrict__ qd,
+__global__ __launch_bounds__(64 * TWS_W, RBD_TWS_MINBLOCKS) void rnea_grad_tree_ws_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                                   const T* __restrict__ qdd, T grav, int use_damping,
                                                                   long long B, T* __restrict__ c_out, T* __restrict__ dcdu,
                                                                   T* __restrict__ pws, T* __restrict__ ews) {

@@ -2331,12 +2331,20 @@ int tree_ws_launch(const T*, const T*, const T*, T, int, int64_t, T*, T*, void*)
 template <class T>
 constexpr bool tws_built() {
   using namespace rbdk;
+#ifdef RBD_TWS_FORCE                                          // experiments: the workspace kernel for every eligible robot
+  return tws_ok<T>();
+#else
   constexpr bool reg_plan = N <= 12 && rbdm::MAXDEPTH <= 5;   // served by rnea_grad_tree_kernel<double>
   if constexpr (!tws_ok<T>() || reg_plan) return false;
   else return GRAD_TREE_DEFAULT || !RBD_FAST_STAGE;
+#endif
 }
 template <class T>
+#ifdef RBD_TWS_FORCE
+constexpr bool tws_only() { return tws_built<T>(); }
+#else
 constexpr bool tws_only() { return tws_built<T>() && rbdk::GRAD_TREE_DEFAULT; }
+#endif
 template <class T, bool HAS_QDD>
 int tree_ws_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* dc_du, void* stream) {
   using namespace rbdk;

@@ -218,6 +218,46 @@ struct TreePlan {
         if (PARENT[r] < 0) { base[rootidx[r]] = w; w += 1 + (side_head[rootidx[r]] >= 0 ? 1 : 0); }
       n_waves = w;
       for (int j = 0; j < N; ++j) wave_of[j] = base[rootidx[j]] + (on_side[j] ? 1 : 0);
+      // Load balance: a root's main wave is the block's critical path (Atlas: neck + left arm + back against one leg on
+      // each leg wave).  A chain-head subtree that hangs off the root's heavy chain AT OR ABOVE the side subtree's parent
+      // is consumed by the main wave only after its block barrier, so any other wave may run it ahead of ITS barrier
+      // (the end of its chains): it goes to the least loaded wave if that shortens the main wave.
+      // cost of a chain: its downward kinematic sweep + twice its upward steps
+      if (w <= 16) {
+        int load[16] = {};
+        for (int hd = 0; hd < N; ++hd)
+          if (head[hd] == hd) load[wave_of[hd]] += DEPTH[leaf[hd]] + 1 + 2 * len[hd];
+        for (int x = 0; x < N; ++x) {
+          const int p = PARENT[x];
+          if (head[x] != x || p < 0) continue;
+          const int sh = side_head[rootidx[x]];
+          if (sh < 0 || on_side[x]) continue;
+          int rt = x;
+          while (PARENT[rt] >= 0) rt = PARENT[rt];
+          if (head[p] != rt) continue;
+          bool above = false;
+          for (int y = PARENT[sh]; y >= 0; y = PARENT[y]) above = above || y == p;
+          if (!above) continue;
+          int cost = 0;
+          for (int hd = 0; hd < N; ++hd) {
+            bool in = false;
+            for (int y = hd; y >= 0; y = PARENT[y]) in = in || y == x;
+            if (in && head[hd] == hd) cost += DEPTH[leaf[hd]] + 1 + 2 * len[hd];
+          }
+          const int wm = wave_of[rt];
+          int best = -1;
+          for (int k = 0; k < w; ++k)
+            if (k != wm && (best < 0 || load[k] < load[best])) best = k;
+          if (best < 0 || load[best] + cost >= load[wm]) continue;
+          for (int j = 0; j < N; ++j) {
+            bool in = false;
+            for (int y = j; y >= 0; y = PARENT[y]) in = in || y == x;
+            if (in) wave_of[j] = best;
+          }
+          load[best] += cost;
+          load[wm] -= cost;
+        }
+      }
       for (int j = 0; j < N; ++j)
         if (head[j] == j && wave_of[j] < 16 && len[j] > wave_len[wave_of[j]]) wave_len[wave_of[j]] = len[j];
       for (int k = 0; k < 16; ++k) inch_off[k + 1] = inch_off[k] + wave_len[k] * (wave_len[k] - 1);
