@@ -481,6 +481,13 @@ def main():
                 ms = time_extra_ms(lambda: ra.rnea_grad(qa, qda, qdda, return_c=True), 20, 3)
                 extra["atlas_rnea_grad_B16384_f32"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
                                                        "alg_GBps": 16384 * (4 * 30 + 2 * 900) * 4 / (ms * 1e-3) / 1e9}
+                # the same robot in the reference's own precision: the workspace tree kernel (rbd_idsva_tree_ws.h)
+                qa8, qda8, qdda8 = make_inputs(16384, 30, 2, dev, torch.float64)
+                ms = time_extra_ms(lambda: ra.rnea_grad(qa8, qda8, qdda8, return_c=True), 10, 2)
+                extra["atlas_rnea_grad_B16384_f64"] = {"ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3),
+                                                       "alg_GBps": 16384 * (4 * 30 + 2 * 900) * 8 / (ms * 1e-3) / 1e9,
+                                                       "kernel": ra._lib.kernel_name(1, 8, 16384)}
+                del qa8, qda8, qdda8
                 rq = RBDReference(quadruped_like(), build=False)
                 qq, qdq, qddq = make_inputs(65536, 12, 4, dev, torch.float64)
                 ms1 = time_extra_ms(lambda: rq.rnea_grad(qq, qdq, qddq, return_c=True), 10, 2)

@@ -10,7 +10,12 @@
  *
  * Conventions
  *   - every data pointer is a DEVICE pointer to a dense row-major array, batch index outermost;
- *     the caller owns all buffers; nothing is allocated per call;
+ *     the caller owns all buffers; nothing is allocated per call -- with ONE exception: rbd_rnea_grad_f64 /
+ *     rbd_rnea_with_grad_f64 of a tree too big for registers and LDS (the 30-body humanoid; rbd_kernel_name says
+ *     rnea_grad_tree_ws_kernel) keeps a LIBRARY-OWNED scratch buffer per (device, stream), sized by what is resident
+ *     at once, not by B (126 MB for that robot): allocated (hipMalloc) by the first such call on a stream, reused by
+ *     every later one, never freed.  Make one such call on a stream before capturing calls on it into a hipGraph;
+ *     calls on different streams use different buffers, calls on one stream are ordered and share one;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous; the
  *     calling thread's CURRENT device must be the stream's device (as for any HIP launch): per-kernel
  *     launch attributes and grid sizes are cached per current device;
