@@ -12,6 +12,9 @@ which = sys.argv[1:] or ["atlas", "quad", "iiwa", "fb"]
 if "atlas" in which:
     r = RBDReference(atlas_like(), build=False); q, qd, qdd = inputs(16384, 30, 2, torch.float32)
     for _ in range(REPS): r.minv(q); r.rnea(q, qd, qdd); r.rnea_grad(q, qd, qdd, return_c=True); r.aba(q, qd, qdd)
+if "atlas64" in which or not sys.argv[1:]:   # the 30-body robot in the reference's own precision: workspace tree kernel (DESIGN 3.1 c')
+    r = RBDReference(atlas_like(), build=False); q, qd, qdd = inputs(16384, 30, 2, torch.float64)
+    for _ in range(REPS): r.rnea_grad(q, qd, qdd, return_c=True)
 if "quad" in which:
     r = RBDReference(quadruped_like(), build=False); q, qd, qdd = inputs(65536, 12, 4, torch.float64)
     for _ in range(REPS): r.rnea_grad(q, qd, qdd, return_c=True); r.minv(q)
