@@ -323,21 +323,11 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void rnea_grad_fbw_kernel(const T* _
     FBW_WAVE_SYNC();
     if (factive) {
       if constexpr (WIDE) {
-        const V4* src = reinterpret_cast<const V4*>(rowimg);
-        V4* dst = reinterpret_cast<V4*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW);
-#pragma unroll 4
-        for (int c0 = 0; c0 < 64; c0 += CPI) {
-          const int cfg = c0 + fsub;
-          if (cfg < nvalid) dst[(long long)cfg * (NV * FBW_ROW / 4) + fe] = src[cfg * (FBW_KP / 4) + fe];
-        }
+        flush_image_rows<CPI, FBW_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW),
+                                          (long long)(NV * FBW_ROW / 4), fsub, fe, nvalid);
       } else {
-        const V2* src = reinterpret_cast<const V2*>(rowimg);
-        V2* dst = reinterpret_cast<V2*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW);
-#pragma unroll 4
-        for (int c0 = 0; c0 < 64; c0 += CPI) {
-          const int cfg = c0 + fsub;
-          if (cfg < nvalid) dst[(long long)cfg * (NV * FBW_ROW / 2) + fe] = src[cfg * (FBW_KP / 2) + fe];
-        }
+        flush_image_rows<CPI, FBW_KP / 2>(reinterpret_cast<const V2*>(rowimg), reinterpret_cast<V2*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW),
+                                          (long long)(NV * FBW_ROW / 2), fsub, fe, nvalid);
       }
     }
   };

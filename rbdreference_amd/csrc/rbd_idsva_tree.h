@@ -254,23 +254,21 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
+#ifdef RBD_TREE_EXP_NOFLUSH      // timing experiment: rows stay in the image (results are wrong)
+          if (factive && use_damping == 12345) {
+#else
           if (factive) {
+#endif
             if constexpr (WIDE) {
-              const V4* src = reinterpret_cast<const V4*>(rowimg);
-              V4* dst = reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N));
-#pragma unroll 4
-              for (int c0 = 0; c0 < 64; c0 += CPI) {
-                const int cfg = c0 + fsub;
-                if (cfg < nvalid) dst[(long long)cfg * (N * N / 2) + fe] = src[cfg * (TREE_KP / 4) + fe];
-              }
+#ifdef RBD_TREE_EXP_L2ONLY       // timing experiment: every block writes block 0's region (stays in L2; results are wrong)
+              flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (0 * N + j) * (2 * N)),
+#else
+              flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N)),
+#endif
+                                                 (long long)(N * N / 2), fsub, fe, nvalid);
             } else {
-              const V2* src = reinterpret_cast<const V2*>(rowimg);
-              V2* dst = reinterpret_cast<V2*>(dcdu + (cfg0 * N + j) * (2 * N));
-#pragma unroll 4
-              for (int c0 = 0; c0 < 64; c0 += CPI) {
-                const int cfg = c0 + fsub;
-                if (cfg < nvalid) dst[(long long)cfg * (N * N) + fe] = src[cfg * TREE_KP2 + fe];
-              }
+              flush_image_rows<CPI, TREE_KP2>(reinterpret_cast<const V2*>(rowimg), reinterpret_cast<V2*>(dcdu + (cfg0 * N + j) * (2 * N)),
+                                              (long long)(N * N), fsub, fe, nvalid);
             }
           }
           // step back to the parent inside the chain, or park the finished chain's composite

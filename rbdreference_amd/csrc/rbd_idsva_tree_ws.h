@@ -60,12 +60,22 @@ struct TwsRef {   // pw(slot) = x;  x = pw(slot);
   RBD_DEV operator T() const {
     static_assert(sizeof(T) == 8, "workspace kernel: fp64 only");
     typedef unsigned U2 __attribute__((ext_vector_type(2)));
+#ifdef RBD_TWS_EXP_NOLOAD        // timing experiment: no workspace reads (results are wrong)
+    T r;
+    asm volatile("; no load" : "=v"(r) : "v"(b.voff));   // stays where the load was: volatile, ordered with the clobbers
+    return r;
+#else
     const U2 v = __builtin_amdgcn_raw_buffer_load_b64(b.rs, b.voff, slot * 64 * (int)sizeof(T), 0);
     return __builtin_bit_cast(T, v);
+#endif
   }
   RBD_DEV void operator=(T x) const {
     typedef unsigned U2 __attribute__((ext_vector_type(2)));
+#ifdef RBD_TWS_EXP_NOSTORE       // timing experiment: no workspace writes (results are wrong)
+    asm volatile("" :: "v"(x));
+#else
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2, x), b.rs, b.voff, slot * 64 * (int)sizeof(T), 0);
+#endif
   }
 };
 
@@ -287,23 +297,17 @@ __global__ __launch_bounds__(64 * TWS_W, RBD_TWS_MINBLOCKS) void rnea_grad_tree_
           });
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
+#ifdef RBD_TWS_EXP_NOFLUSH       // timing experiment: rows stay in the image (results are wrong)
+          if (factive && use_damping == 12345) {
+#else
           if (factive) {
+#endif
             if constexpr (WIDE) {
-              const V4* src = reinterpret_cast<const V4*>(rowimg);
-              V4* dst = reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N));
-#pragma unroll 4
-              for (int c0 = 0; c0 < 64; c0 += CPI) {
-                const int cfg = c0 + fsub;
-                if (cfg < nvalid) dst[(long long)cfg * (N * N / 2) + fe] = src[cfg * (TREE_KP / 4) + fe];
-              }
+              flush_image_rows<CPI, TREE_KP / 4, false>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N)),
+                                                 (long long)(N * N / 2), fsub, fe, nvalid);
             } else {
-              const V2* src = reinterpret_cast<const V2*>(rowimg);
-              V2* dst = reinterpret_cast<V2*>(dcdu + (cfg0 * N + j) * (2 * N));
-#pragma unroll 4
-              for (int c0 = 0; c0 < 64; c0 += CPI) {
-                const int cfg = c0 + fsub;
-                if (cfg < nvalid) dst[(long long)cfg * (N * N) + fe] = src[cfg * (TREE_KP / 2) + fe];
-              }
+              flush_image_rows<CPI, TREE_KP / 2, false>(reinterpret_cast<const V2*>(rowimg), reinterpret_cast<V2*>(dcdu + (cfg0 * N + j) * (2 * N)),
+                                                 (long long)(N * N), fsub, fe, nvalid);
             }
           }
           // step back to the parent inside the chain, or park the finished chain's composite
