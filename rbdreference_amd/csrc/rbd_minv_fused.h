@@ -208,7 +208,9 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
   sfor<0, MF_W>([&](auto W) {
     constexpr int w = decltype(W)::value;
     if constexpr (w <= NL) {
+#ifndef RBD_MF_EXP_NOB            // timing experiment: no column phase (results are wrong)
       if (wave == w) minv_cols_class<T, RT, w, MF_CPB>(recs, tile, dense, lane, slot, j, spare);
+#endif
     }
   });
   __syncthreads();
@@ -223,7 +225,11 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
       qdd_out[(cfg0 + slot) * N + j] = o;
     }
   }
+#ifdef RBD_MF_EXP_NOEPI            // timing experiment: the torso's rows are not written (results are wrong)
+  if (Minv != nullptr && dense == 12345) {
+#else
   if (Minv != nullptr) {
+#endif
     constexpr int RW = rows * N;
     T* gdst = Minv + cfg0 * (N * N) + row0 * N;
     auto elem = [&](int cfg, int e) -> T {
@@ -234,17 +240,7 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
       return own ? x : T(0);
     };
     if constexpr (minv_vec_flush(RT) && sizeof(T) == 4) {
-      typedef T V __attribute__((ext_vector_type(4)));
-      constexpr int RV = RW / 4;
-      const int total = nvalid * RV;
-#pragma unroll 2
-      for (int g = tid; g < total; g += NT) {
-        const int cfg = g / RV;
-        const int r4 = g - cfg * RV;
-        V x;
-        x[0] = elem(cfg, 4 * r4); x[1] = elem(cfg, 4 * r4 + 1); x[2] = elem(cfg, 4 * r4 + 2); x[3] = elem(cfg, 4 * r4 + 3);
-        reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
-      }
+      minv_own_rows_flush<T, row0, rows, MF_CPB, TS, NT>(tile, gdst, tid, nvalid);
     } else {
       const int total = nvalid * RW;
 #pragma unroll 4
@@ -273,8 +269,13 @@ __global__ __launch_bounds__(64 * MF_W, 2) void minv_fused_kernel(const T* __res
       if (!done) {
         if (blk < nb) {
           if constexpr (mcl_limbs(rt) > 0) {
+#ifndef RBD_MF_EXP_NOTORSO        // timing experiment: the blocks of groups with limbs do nothing
             mf_limbs_group<T, rt>(q, B, dense, Minv, u_in, c_in, qdd_out, blk, smem);
+#endif
           } else {
+#ifdef RBD_MF_EXP_NOLEGS          // timing experiment: the blocks of small groups do nothing
+            if (dense != 12345) return;
+#endif
             // a small group: every wave of the block is an independent 8-configuration unit of ia8_group's fused path
             const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
             constexpr int r0 = grp_row0(rt);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Variant builds of ONE gradient unit for tools/exp_grad.py: COMMON + the GRAD unit of a precision (fast stage) with
+"""Variant builds of ONE unit (UNIT=GRAD | MINV | ..., default GRAD) for tools/exp_grad.py: COMMON + the GRAD unit of a precision (fast stage) with
 extra flags + stubs for everything else, linked as  librbd_<robot>_<hash>.<tag>.so  (seconds to a minute per variant
 instead of the whole library).
 
@@ -27,7 +27,7 @@ def main():
     base = [hipcc_path(), *[f for f in HIPCC_FLAGS if f != "-shared"], "-DRBD_TU_SPLIT=1", "-include", hdr]
     tmp = os.path.join(BUILD_DIR, "exp_tws")
     os.makedirs(tmp, exist_ok=True)
-    unit = f"GRAD_{prec}"
+    unit = f"{os.environ.get('UNIT', 'GRAD')}_{prec}"
     missing = [f"{u}_{q}" for u in _ALL_FAMILY_UNITS for q in ("F32", "F64") if f"{u}_{q}" != unit]
 
     def cc(defs, out):
@@ -39,10 +39,10 @@ def main():
 
     def variant(spec):
         tag, fl = spec
-        obj = cc([f"-DRBD_TU_{unit}=1", "-DRBD_FAST_STAGE=1", *[f for f in fl.split(",") if f]], os.path.join(tmp, f"{tag}_{m.hash}.o"))
+        obj = cc([f"-DRBD_TU_{unit}=1", *(["-DRBD_FAST_STAGE=1"] if unit.startswith("GRAD") else []), *[f for f in fl.split(",") if f]], os.path.join(tmp, f"{tag}_{m.hash}.o"))
         out = lib_path(m)[:-3] + f".{tag}.so"
         subprocess.run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", common, stubs, obj, "-o", out], check=True)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), out, "rnea_grad"], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), out, os.environ.get("KFILTER", "rnea_grad")], capture_output=True, text=True)
         return out + "\n" + r.stdout
 
     with ThreadPoolExecutor(4) as ex:
