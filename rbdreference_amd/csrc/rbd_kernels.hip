@@ -1213,6 +1213,9 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
     });
   }
   __syncthreads();
+#ifdef RBD_GRAD_EXP_NOFLUSH       // timing experiment: the group's rows stay in the tile (results are wrong)
+  if (use_damping == 12345)
+#endif
   {
     constexpr int RW = rows * GRAD_ROW;                         // elements of this group per configuration
     T* gdst = dcdu + cfg0 * GRAD_TILE + row0 * GRAD_ROW;
