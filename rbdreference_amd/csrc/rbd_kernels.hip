@@ -1408,6 +1408,12 @@ constexpr int minv_cpb(int rt) { return 64 / minv_lc(grp_rows(rt)); }           
 // LDS tile stride between the configurations of a block: a multiple of 4 scalars (+4) when the group's rows
 // can leave as 16-byte pieces, otherwise odd
 constexpr bool minv_vec_flush(int rt) { return (grp_rows(rt) * N) % 4 == 0 && (N * N) % 4 == 0 && (grp_row0(rt) * N) % 4 == 0; }
+// the same for 16-byte pieces of T (4 floats / 2 doubles): a configuration's segment of the group's rows starts and ends on 16-byte boundaries
+template <class T>
+constexpr bool minv_piece_flush(int rt) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  return (grp_rows(rt) * N) % VE == 0 && (N * N) % VE == 0 && (grp_row0(rt) * N) % VE == 0;
+}
 constexpr int minv_ts(int rt) { return minv_vec_flush(rt) ? grp_rows(rt) * N + 4 : (grp_rows(rt) * N) | 1; }
 // the column phase's LDS tile holds only the group's OWN columns ([rows][rows] per configuration): the other
 // groups' columns are structural zeros, generated at the flush (9.1 -> 6.5 KB per Atlas torso block: 6
@@ -1633,19 +1639,9 @@ RBD_DEV void minv_cols_group(const T* __restrict__ ws, long long B, int dense, T
       const T x = tile[cfg * TS + r * rows + (own ? c : 0)];
       return own ? x : T(0);
     };
-    if constexpr (minv_vec_flush(RT) && sizeof(T) == 4) {
+    if constexpr (minv_piece_flush<T>(RT)) {
       // 16-byte pieces: the segment of a configuration is 16-byte aligned at both ends
-      typedef T V __attribute__((ext_vector_type(4)));
-      constexpr int RV = RW / 4;
-      const int total = nvalid * RV;
-#pragma unroll 2
-      for (int g = lane; g < total; g += 64) {
-        const int cfg = g / RV;
-        const int r4 = g - cfg * RV;
-        V x;
-        x[0] = elem(cfg, 4 * r4); x[1] = elem(cfg, 4 * r4 + 1); x[2] = elem(cfg, 4 * r4 + 2); x[3] = elem(cfg, 4 * r4 + 3);
-        reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
-      }
+      minv_own_rows_flush<T, row0, rows, CPB, TS, 64>(tile, gdst, lane, nvalid);
     } else {
       const int total = nvalid * RW;
 #pragma unroll 4
@@ -1826,18 +1822,8 @@ RBD_DEV void minv_cols_limbs(const T* __restrict__ ws, long long B, int dense, T
       const T x = tile[cfg * TS + r * rows + (own ? c : 0)];
       return own ? x : T(0);
     };
-    if constexpr (minv_vec_flush(RT) && sizeof(T) == 4) {
-      typedef T V __attribute__((ext_vector_type(4)));
-      constexpr int RV = RW / 4;
-      const int total = nvalid * RV;
-#pragma unroll 2
-      for (int g = tid; g < total; g += NT) {
-        const int cfg = g / RV;
-        const int r4 = g - cfg * RV;
-        V x;
-        x[0] = elem(cfg, 4 * r4); x[1] = elem(cfg, 4 * r4 + 1); x[2] = elem(cfg, 4 * r4 + 2); x[3] = elem(cfg, 4 * r4 + 3);
-        reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
-      }
+    if constexpr (minv_piece_flush<T>(RT)) {
+      minv_own_rows_flush<T, row0, rows, CPB, TS, NT>(tile, gdst, tid, nvalid);
     } else {
       const int total = nvalid * RW;
 #pragma unroll 4

@@ -239,7 +239,7 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
       const T x = tile[cfg * TS + r * rows + (own ? cx : 0)];
       return own ? x : T(0);
     };
-    if constexpr (minv_vec_flush(RT) && sizeof(T) == 4) {
+    if constexpr (minv_piece_flush<T>(RT)) {
       minv_own_rows_flush<T, row0, rows, MF_CPB, TS, NT>(tile, gdst, tid, nvalid);
     } else {
       const int total = nvalid * RW;

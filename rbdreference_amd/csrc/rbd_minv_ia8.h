@@ -56,69 +56,6 @@ constexpr int last_child_of(int p) {   // the child of p with the largest index 
 constexpr bool minv_small_group(int rt) { return GRAD_PER_ROOT && grp_rows(rt) <= 8; }
 constexpr int IA8_TS = 8 * 8 + 1;              // LDS tile stride of a small group's [rows][rows] block
 
-// Rows R0 .. R0 + RN - 1 of Minv for NCFG configurations, from an LDS tile that holds only the group's OWN columns
-// ([cfg][r * RN + c], configuration stride TS) to HBM as 16-byte pieces (the other groups' columns are structural
-// zeros).  FULL blocks: thread t owns piece r4 = t of a configuration's RN * N / 4 pieces -- its four tile offsets and
-// "own column" flags are computed ONCE, and every pass is four LDS reads, four selects and one store.  (The generic
-// loop  g = tid, tid + NT, ...  divides by RN * N / 4 and by N four times in every iteration: 50 instructions per piece,
-// a fifth of the one-launch kernel's instruction stream and 6 of its 29 us on the 30-body robot.)
-template <class T, int R0, int RN, int NCFG, int TS, int NT>
-RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid) {
-  static_assert(sizeof(T) == 4 && (RN * N) % 4 == 0, "16-byte pieces of fp32 rows");
-  typedef T V __attribute__((ext_vector_type(4)));
-  constexpr int RV = RN * N / 4;
-  if constexpr (RV <= NT) {
-    if (nvalid == NCFG) {
-      constexpr int K = NT / RV;                          // configurations per pass
-      constexpr int PASSES = (NCFG + K - 1) / K;
-      const int sub = tid / RV, r4 = tid - sub * RV;
-      if (sub < K) {
-        int off[4];
-        bool own[4];
-        sfor<0, 4>([&](auto I_) {
-          constexpr int i = decltype(I_)::value;
-          const int e = 4 * r4 + i;
-          const int r = e / N;
-          const int cidx = e - r * N - R0;
-          own[i] = cidx >= 0 && cidx < RN;
-          off[i] = r * RN + (own[i] ? cidx : 0);
-        });
-        V buf[PASSES];
-        sfor<0, PASSES>([&](auto P_) {
-          constexpr int p = decltype(P_)::value;
-          const int cfg = p * K + sub;
-          const int cc = (p + 1) * K <= NCFG ? cfg : (cfg < NCFG ? cfg : NCFG - 1);
-          sfor<0, 4>([&](auto I_) { constexpr int i = decltype(I_)::value; buf[p][i] = tile[cc * TS + off[i]]; });
-        });
-        sfor<0, PASSES>([&](auto P_) {
-          constexpr int p = decltype(P_)::value;
-          const int cfg = p * K + sub;
-          V x;
-          sfor<0, 4>([&](auto I_) { constexpr int i = decltype(I_)::value; x[i] = own[i] ? buf[p][i] : T(0); });
-          if ((p + 1) * K <= NCFG || cfg < NCFG) reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
-        });
-      }
-      return;
-    }
-  }
-  auto elem = [&](int cfg, int e) -> T {                 // (row e / N, column e % N): own columns from the tile, the rest zero
-    const int r = e / N;
-    const int cidx = e - r * N - R0;
-    const bool own = cidx >= 0 && cidx < RN;
-    const T x = tile[cfg * TS + r * RN + (own ? cidx : 0)];
-    return own ? x : T(0);
-  };
-  const int total = nvalid * RV;
-#pragma unroll 2
-  for (int g = tid; g < total; g += NT) {
-    const int cfg = g / RV;
-    const int r4 = g - cfg * RV;
-    V x;
-    x[0] = elem(cfg, 4 * r4); x[1] = elem(cfg, 4 * r4 + 1); x[2] = elem(cfg, 4 * r4 + 2); x[3] = elem(cfg, 4 * r4 + 3);
-    reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
-  }
-}
-
 // One group (root subtree) RT for the 8 configurations cfg0 .. cfg0 + 7, by ONE wave: `lane` = lane of that wave,
 // tr_lds [64 * 6], im_lds [N * 36], tile_s [8 * IA8_TS], tau_s [64] = LDS of that wave (im_lds may be shared by
 // waves that work on the same group).  Contains block barriers: every wave of the block must call it.
@@ -282,7 +219,7 @@ RBD_DEV void ia8_group(const T* __restrict__ q, long long B, T* __restrict__ ws,
           const T x = tile_s[cfg * IA8_TS + r * RN + (own ? cidx : 0)];
           return own ? x : T(0);
         };
-        if constexpr (minv_vec_flush(rt) && sizeof(T) == 4) {
+        if constexpr (minv_piece_flush<T>(rt)) {
           minv_own_rows_flush<T, R0, RN, 8, IA8_TS, 64>(tile_s, gdst, lane, nvalid);
         } else {
           const int total = nvalid * RW;

@@ -379,4 +379,68 @@ RBD_DEV void rnea_fwd_body(const JTrig<T>& g, T qd, T qdd, T grav, const T (&vp)
   fxv<true>(v, Iv, f);         // f = I a + crf(v) I v   (:595-596)
 }
 
+// Rows R0 .. R0 + RN - 1 of Minv for NCFG configurations, from an LDS tile that holds only the group's OWN columns
+// ([cfg][r * RN + c], configuration stride TS) to HBM as 16-byte pieces (4 floats or 2 doubles; the other groups' columns are structural
+// zeros).  FULL blocks: thread t owns piece r4 = t of a configuration's RN * N / 4 pieces -- its four tile offsets and
+// "own column" flags are computed ONCE, and every pass is four LDS reads, four selects and one store.  (The generic
+// loop  g = tid, tid + NT, ...  divides by RN * N / 4 and by N four times in every iteration: 50 instructions per piece,
+// a fifth of the one-launch kernel's instruction stream and 6 of its 29 us on the 30-body robot.)
+template <class T, int R0, int RN, int NCFG, int TS, int NT>
+RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  static_assert((RN * N) % VE == 0, "16-byte pieces");
+  typedef T V __attribute__((ext_vector_type(VE)));
+  constexpr int RV = RN * N / VE;
+  if constexpr (RV <= NT) {
+    if (nvalid == NCFG) {
+      constexpr int K = NT / RV;                          // configurations per pass
+      constexpr int PASSES = (NCFG + K - 1) / K;
+      const int sub = tid / RV, r4 = tid - sub * RV;
+      if (sub < K) {
+        int off[VE];
+        bool own[VE];
+        sfor<0, VE>([&](auto I_) {
+          constexpr int i = decltype(I_)::value;
+          const int e = VE * r4 + i;
+          const int r = e / N;
+          const int cidx = e - r * N - R0;
+          own[i] = cidx >= 0 && cidx < RN;
+          off[i] = r * RN + (own[i] ? cidx : 0);
+        });
+        V buf[PASSES];
+        sfor<0, PASSES>([&](auto P_) {
+          constexpr int p = decltype(P_)::value;
+          const int cfg = p * K + sub;
+          const int cc = (p + 1) * K <= NCFG ? cfg : (cfg < NCFG ? cfg : NCFG - 1);
+          sfor<0, VE>([&](auto I_) { constexpr int i = decltype(I_)::value; buf[p][i] = tile[cc * TS + off[i]]; });
+        });
+        sfor<0, PASSES>([&](auto P_) {
+          constexpr int p = decltype(P_)::value;
+          const int cfg = p * K + sub;
+          V x;
+          sfor<0, VE>([&](auto I_) { constexpr int i = decltype(I_)::value; x[i] = own[i] ? buf[p][i] : T(0); });
+          if ((p + 1) * K <= NCFG || cfg < NCFG) reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
+        });
+      }
+      return;
+    }
+  }
+  auto elem = [&](int cfg, int e) -> T {                 // (row e / N, column e % N): own columns from the tile, the rest zero
+    const int r = e / N;
+    const int cidx = e - r * N - R0;
+    const bool own = cidx >= 0 && cidx < RN;
+    const T x = tile[cfg * TS + r * RN + (own ? cidx : 0)];
+    return own ? x : T(0);
+  };
+  const int total = nvalid * RV;
+#pragma unroll 2
+  for (int g = tid; g < total; g += NT) {
+    const int cfg = g / RV;
+    const int r4 = g - cfg * RV;
+    V x;
+    sfor<0, VE>([&](auto I_) { constexpr int i = decltype(I_)::value; x[i] = elem(cfg, VE * r4 + i); });
+    reinterpret_cast<V*>(gdst + (long long)cfg * (N * N))[r4] = x;
+  }
+}
+
 }  // namespace rbdk
