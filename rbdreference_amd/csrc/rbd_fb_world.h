@@ -309,6 +309,8 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void rnea_grad_fbw_kernel(const T* _
   constexpr int CPI = 64 / FW > 0 ? 64 / FW : 1;          // configurations per flush step
   const int fsub = lane / FW, fe = lane - fsub * FW;
   const bool factive = lane < CPI * FW;
+  // full tiles store through a descriptor of the block's 64 matrices (rbd_world.h: flush_image_rows_buf)
+  const __amdgpu_buffer_rsrc_t out_rs = out_tile_rsrc(dcdu + cfg0 * NV * (long long)FBW_ROW, 64 * NV * FBW_ROW * (int)sizeof(T));
   // row[2 nv] of matrix row `mrow` -> image -> dc_du[b][mrow][:]
   auto flush_row = [&](const T (&row)[FBW_ROW], int mrow) {
     FBW_WAVE_SYNC();
@@ -323,7 +325,11 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void rnea_grad_fbw_kernel(const T* _
     FBW_WAVE_SYNC();
     if (factive) {
       if constexpr (WIDE) {
-        flush_image_rows<CPI, FBW_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW),
+        if (nvalid == 64) {
+          flush_image_rows_buf<CPI, FBW_KP / 4>(reinterpret_cast<const V4*>(rowimg), out_rs, (fsub * (NV * FBW_ROW / 4) + fe) * 16,
+                                                mrow * FBW_ROW * (int)sizeof(T), NV * FBW_ROW * (int)sizeof(T), fsub, fe);
+        } else
+        flush_image_rows<CPI, FBW_KP / 4, false>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW),
                                           (long long)(NV * FBW_ROW / 4), fsub, fe, nvalid);
       } else {
         flush_image_rows<CPI, FBW_KP / 2>(reinterpret_cast<const V2*>(rowimg), reinterpret_cast<V2*>(dcdu + (cfg0 * NV + mrow) * (long long)FBW_ROW),

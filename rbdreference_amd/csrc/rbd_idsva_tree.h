@@ -25,6 +25,9 @@
 #pragma once
 #include "rbd_idsva.h"
 
+#ifndef RBD_TREE_NO_BUF_FLUSH
+#define RBD_TREE_NO_BUF_FLUSH 0
+#endif
 namespace rbdk {
 
 // ---- LDS plan (scalars of T) -----------------------------------------------------------------------
@@ -127,6 +130,8 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
   const int fsub = lane / FW, fe = lane - fsub * FW;
   const bool factive = lane < CPI * FW;
   const int myroot = blockIdx.y;                          // (single-wave layout) independent root subtrees run in separate blocks
+  // full tiles store through a descriptor of the block's 64 matrices (rbd_world.h: flush_image_rows_buf)
+  const __amdgpu_buffer_rsrc_t out_rs = out_tile_rsrc(dcdu + cfg0 * N * (2 * N), 64 * N * 2 * N * (int)sizeof(T));
 
   sfor_down<0, N>([&](auto H_) {
     constexpr int h = decltype(H_)::value;
@@ -259,7 +264,15 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
 #else
           if (factive) {
 #endif
-            if constexpr (WIDE) {
+            if constexpr (WIDE && sizeof(T) == 4 && !RBD_TREE_NO_BUF_FLUSH) {
+              if (nvalid == 64) {
+                flush_image_rows_buf<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), out_rs, (fsub * (N * N / 2) + fe) * 16,
+                                                      j * 2 * N * (int)sizeof(T), N * 2 * N * (int)sizeof(T), fsub, fe);
+              } else {
+                flush_image_rows<CPI, TREE_KP / 4, false>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N)),
+                                                          (long long)(N * N / 2), fsub, fe, nvalid);
+              }
+            } else if constexpr (WIDE) {
 #ifdef RBD_TREE_EXP_L2ONLY       // timing experiment: every block writes block 0's region (stays in L2; results are wrong)
               flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (0 * N + j) * (2 * N)),
 #else

@@ -511,6 +511,46 @@ RBD_DEV void comp_each(Comp<T>& c, F&& f) {
 // whole batch of steps before their stores: with the tail predicate `cfg < nvalid` inside the loop every step is an
 // exec-masked region of its own, i.e. read -> wait -> store, 16 times per row (measured on the 30-body robot's tree
 // kernel: 3 300 cycles per row on the wave that is the block's critical path, 15 of 36 us at B = 16 384).
+// The same for FULL tiles of 16-byte vectors through a raw-buffer descriptor of the block's output region (base = the
+// block's first configuration, made by the caller once per kernel): a store is  s_mov soffset; buffer_store_dwordx4
+// v, v_lane_offset, s[desc], soffset  instead of a 64-bit per-lane address built with four instructions per store.
+// voff = the lane's byte offset (fsub * dstride + fe) * 16, soff = the row's byte offset in a configuration's matrix.
+template <int CPI, int SST, class V>
+RBD_DEV void flush_image_rows_buf(const V* src, __amdgpu_buffer_rsrc_t rs, int voff, int soff, int dstride_bytes, int fsub, int fe) {
+  static_assert(sizeof(V) == 16, "16-byte vectors");
+  typedef unsigned U4 __attribute__((ext_vector_type(4)));
+  constexpr int IT = (64 + CPI - 1) / CPI;
+  constexpr int BATCH = 16 < IT ? 16 : IT;
+  sfor<0, (IT + BATCH - 1) / BATCH>([&](auto G_) {
+    constexpr int g = decltype(G_)::value;
+    V buf[BATCH];
+    sfor<0, BATCH>([&](auto I_) {
+      constexpr int i = decltype(I_)::value, it = g * BATCH + i;
+      if constexpr (it < IT) {
+        const int cfg = it * CPI + fsub;
+        if constexpr ((it + 1) * CPI <= 64) buf[i] = src[cfg * SST + fe];
+        else buf[i] = src[(cfg < 64 ? cfg : 63) * SST + fe];
+      }
+    });
+    sfor<0, BATCH>([&](auto I_) {
+      constexpr int i = decltype(I_)::value, it = g * BATCH + i;
+      if constexpr (it < IT) {
+        if constexpr ((it + 1) * CPI <= 64) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, buf[i]), rs, voff, soff + it * CPI * dstride_bytes, 0);
+        } else {
+          if (it * CPI + fsub < 64) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, buf[i]), rs, voff, soff + it * CPI * dstride_bytes, 0);
+        }
+      }
+    });
+  });
+}
+template <class T>
+RBD_DEV __amdgpu_buffer_rsrc_t out_tile_rsrc(T* base, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
 // BATCHED = false keeps the plain loop (the fp64 workspace kernel, at 460 of 512 registers, lost 3 % with the staging).
 template <int CPI, int SST, bool BATCHED = true, class V>
 RBD_DEV void flush_image_rows(const V* src, V* dst, long long dstride, int fsub, int fe, int nvalid) {
