@@ -405,23 +405,7 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void rnea_grad_fbw_kernel(const T* _
             if (c_out != nullptr && lane < nvalid) c_out[b * NV + j + 5] = cj;
             // t-vectors (:1481-1484)
             T t1[6], t2[6], t3[6], t4[6];
-            {
-              T y3[6], s1[6], z1[6], zf[6], y2[6], s2[6], z2[6];
-              rin_apply(C.IC, Sv[j], t1);
-              rin_apply(C.IC, Pdd[j], y3);
-              sym_apply(C.SC, Sv[j], s1);
-              fxv<false>(Sv[j], C.pm, z1);
-              fxv<false>(Sv[j], C.f, zf);
-              rin_apply(C.IC, Pd[j], y2);
-              sym_apply(C.SC, Pd[j], s2);
-              fxv<false>(Pd[j], C.pm, z2);
-              sfor<0, 6>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                t4[r] = s1[r] - z1[r];
-                t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
-                t2[r] = fma_(T(2), y2[r], s1[r] + z1[r]);
-              });
-            }
+            tvectors<false>(C, Sv[j], Pd[j], Pdd[j], t1, t2, t3, t4);
             // ---- row j + 5 --------------------------------------------------------------------------------
             T row[FBW_ROW];
             {
@@ -442,7 +426,7 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void rnea_grad_fbw_kernel(const T* _
             sfor<1, N>([&](auto C_) {
               constexpr int c = decltype(C_)::value;
               if constexpr (is_anc_or_self(c, j)) {
-                T dq = dot6(t4, Pd[c]) + dot6(t1, Pdd[c]);
+                T dq = dot6_acc(t1, Pdd[c], dot6(t4, Pd[c]));
                 T dqd = fma_(T(2), dot6(t1, Pd[c]), dot6(t4, Sv[c]));
                 row[c + 5] = dq;
                 row[NV + c + 5] = dqd;

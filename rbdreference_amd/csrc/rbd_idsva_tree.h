@@ -188,33 +188,7 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
           if (c_out != nullptr && lane < nvalid) c_out[b * N + j] = cj;
           // t-vectors (:1481-1484)
           T t1[6], t2[6], t3[6], t4[6];
-          {
-            T y3[6], s1[6], z1[6], zf[6];
-            rin_apply(C.IC, Sv[j], t1);
-            rin_apply(C.IC, Pdd[j], y3);
-            sym_apply(C.SC, Sv[j], s1);
-            fxv<false>(Sv[j], C.pm, z1);
-            fxv<false>(Sv[j], C.f, zf);
-            if constexpr (PARENT[j] < 0) {   // psid of a root is identically zero
-              sfor<0, 6>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                t4[r] = s1[r] - z1[r];
-                t3[r] = y3[r] + zf[r];
-                t2[r] = s1[r] + z1[r];
-              });
-            } else {
-              T y2[6], s2[6], z2[6];
-              rin_apply(C.IC, Pd[j], y2);
-              sym_apply(C.SC, Pd[j], s2);
-              fxv<false>(Pd[j], C.pm, z2);
-              sfor<0, 6>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                t4[r] = s1[r] - z1[r];
-                t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
-                t2[r] = fma_(T(2), y2[r], s1[r] + z1[r]);
-              });
-            }
-          }
+          tvectors<(PARENT[j] < 0)>(C, Sv[j], Pd[j], Pdd[j], t1, t2, t3, t4);
           // ---- row j ------------------------------------------------------------------------------------
           T row[2 * N];
           sfor<0, N>([&](auto C_) {
@@ -225,7 +199,7 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
                 dq = fma_(t1[3], Pdd[c][3], t1[4] * Pdd[c][4]);
                 dqd = dot6(t4, Sv[c]);
               } else {
-                dq = dot6(t4, Pd[c]) + dot6(t1, Pdd[c]);
+                dq = dot6_acc(t1, Pdd[c], dot6(t4, Pd[c]));
                 dqd = fma_(T(2), dot6(t1, Pd[c]), dot6(t4, Sv[c]));
               }
               if constexpr (c == j) dqd += sel(use_damping != 0, T(DAMPING[j]), T(0));   // (:1336-1341)

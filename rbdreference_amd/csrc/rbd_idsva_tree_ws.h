@@ -209,33 +209,7 @@ __global__ __launch_bounds__(64 * TWS_W, RBD_TWS_MINBLOCKS) void rnea_grad_tree_
           if (c_out != nullptr && lane < nvalid) c_out[b * N + j] = cj;
           // t-vectors (:1481-1484)
           T t1[6], t2[6], t3[6], t4[6];
-          {
-            T y3[6], s1[6], z1[6], zf[6];
-            rin_apply(C.IC, Sj, t1);
-            rin_apply(C.IC, Pddj, y3);
-            sym_apply(C.SC, Sj, s1);
-            fxv<false>(Sj, C.pm, z1);
-            fxv<false>(Sj, C.f, zf);
-            if constexpr (PARENT[j] < 0) {   // psid of a root is identically zero
-              sfor<0, 6>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                t4[r] = s1[r] - z1[r];
-                t3[r] = y3[r] + zf[r];
-                t2[r] = s1[r] + z1[r];
-              });
-            } else {
-              T y2[6], s2[6], z2[6];
-              rin_apply(C.IC, Pdj, y2);
-              sym_apply(C.SC, Pdj, s2);
-              fxv<false>(Pdj, C.pm, z2);
-              sfor<0, 6>([&](auto R_) {
-                constexpr int r = decltype(R_)::value;
-                t4[r] = s1[r] - z1[r];
-                t3[r] = (s2[r] + z2[r]) + (y3[r] + zf[r]);
-                t2[r] = fma_(T(2), y2[r], s1[r] + z1[r]);
-              });
-            }
-          }
+          tvectors<(PARENT[j] < 0)>(C, Sj, Pdj, Pddj, t1, t2, t3, t4);
           // ---- row j, straight into the image (the wave's LDS operations execute in order: the previous row's
           //      flush reads are ahead of these writes) ---------------------------------------------------------
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -283,7 +257,7 @@ __global__ __launch_bounds__(64 * TWS_W, RBD_TWS_MINBLOCKS) void rnea_grad_tree_
               dq = fma_(t1[3], Pddc[3], t1[4] * Pddc[4]);
               dqd = dot6(t4, Sc);
             } else {
-              dq = dot6(t4, Pdc) + dot6(t1, Pddc);
+              dq = dot6_acc(t1, Pddc, dot6(t4, Pdc));
               dqd = fma_(T(2), dot6(t1, Pdc), dot6(t4, Sc));
             }
             if constexpr (c == j) dqd += sel(use_damping != 0, T(DAMPING[j]), T(0));   // (:1336-1341)

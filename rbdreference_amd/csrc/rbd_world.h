@@ -352,13 +352,12 @@ RBD_DEV void ws_down(WState<T>& s, const JTrig<T>& g, T qd, T qdd, T grav, T (&S
     });
     s.a[5] -= grav;
   } else {
-    T t1[6], t2[6];
+    T t1[6];
     crm6(s.v, Sv, Pd);
     crm6(s.a, Sv, t1);
-    crm6(s.v, Pd, t2);
+    crm6_add(s.v, Pd, t1, Pdd);                  // (accumulate forms: the join is part of the FMA chain)
     sfor<0, 6>([&](auto R_) {
       constexpr int r = decltype(R_)::value;
-      Pdd[r] = t1[r] + t2[r];
       s.v[r] = fma_(Sv[r], qd, s.v[r]);
       s.a[r] = fma_(Sv[r], qdd, fma_(Pd[r], qd, s.a[r]));
     });
@@ -467,8 +466,7 @@ RBD_DEV void comp_local(const WState<T>& s, Comp<T>& L) {
   T Ia[6];
   rin_apply(L.IC, s.v, L.pm);
   rin_apply(L.IC, s.a, Ia);
-  fxv<false>(s.v, L.pm, L.f);
-  sfor<0, 6>([&](auto R_) { L.f[decltype(R_)::value] += Ia[decltype(R_)::value]; });
+  fxv_add(s.v, L.pm, Ia, L.f);
   {
     const T w[3] = {s.v[0], s.v[1], s.v[2]}, u[3] = {s.v[3], s.v[4], s.v[5]};
     const T Ifull[3][3] = {{L.IC.I[0], L.IC.I[1], L.IC.I[2]}, {L.IC.I[1], L.IC.I[3], L.IC.I[4]}, {L.IC.I[2], L.IC.I[4], L.IC.I[5]}};
@@ -492,6 +490,33 @@ RBD_DEV void comp_local(const WState<T>& s, Comp<T>& L) {
     T g[3];
     cross3(w, L.IC.h, g);
     sfor<0, 3>([&](auto R_) { constexpr int r = decltype(R_)::value; L.SC.G[r] = fma_(L.IC.m, u[r], g[r]); });
+  }
+}
+// t-vectors of body J from its composite and its S / psid / psidd (:1481-1484), joins folded into the FMA chains:
+//   t1 = IC S,  t4 = SC S - S x* pm,  t3 = IC psidd + S x* f + SC psid + psid x* pm,  t2 = 2 IC psid + SC S + S x* pm
+template <bool ROOT, class T>
+RBD_DEV void tvectors(const Comp<T>& C, const T (&Sj)[6], const T (&Pdj)[6], const T (&Pddj)[6], T (&t1)[6], T (&t2)[6], T (&t3)[6], T (&t4)[6]) {
+  T y3[6], s1[6], yf[6];
+  rin_apply(C.IC, Sj, t1);
+  sym_apply(C.SC, Sj, s1);
+  fxv_sub(Sj, C.pm, s1, t4);
+  rin_apply(C.IC, Pddj, y3);
+  fxv_add(Sj, C.f, y3, yf);
+  if constexpr (ROOT) {   // psid of a root is identically zero
+    sfor<0, 6>([&](auto R_) {
+      constexpr int r = decltype(R_)::value;
+      t3[r] = yf[r];
+      t2[r] = fma_(T(2), s1[r], -t4[r]);
+    });
+  } else {
+    T y2[6], ys[6];
+    rin_apply(C.IC, Pdj, y2);
+    sym_apply_acc(C.SC, Pdj, yf, ys);
+    fxv_add(Pdj, C.pm, ys, t3);
+    sfor<0, 6>([&](auto R_) {
+      constexpr int r = decltype(R_)::value;
+      t2[r] = fma_(T(2), y2[r] + s1[r], -t4[r]);
+    });
   }
 }
 // flat view of a composite (31 scalars) for parking
