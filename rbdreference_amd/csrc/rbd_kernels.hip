@@ -1238,6 +1238,18 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
       if (!done) {
         typedef T V __attribute__((ext_vector_type(VE)));
         constexpr int RV = RW / VE;
+#ifndef RBD_GRAD_EXP_OLD_FLUSH
+        if constexpr ((CFGS * RV) % NT == 0) {
+          if (nvalid == CFGS) {   // full tile: no division per piece, batched reads, buffer stores (rbd_spatial.h)
+            flush_cfg_rows_full<T, CFGS, RW, GRAD_TS, GRAD_TILE, NT>(tile, gdst, lane);
+            done = true;
+          }
+        }
+#endif
+      }
+      if (!done) {
+        typedef T V __attribute__((ext_vector_type(VE)));
+        constexpr int RV = RW / VE;
 #pragma unroll 4
         for (int g = lane; g < nvalid * RV; g += NT) {
           const int cfg = g / RV;

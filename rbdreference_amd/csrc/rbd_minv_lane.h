@@ -161,6 +161,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void minv_lane_kernel(c
           done = true;
         }
       }
+      if constexpr (RW % VE == 0 && (N * N) % VE == 0 && (row0 * N) % VE == 0 && (64 * (RW / VE)) % 64 == 0) {
+        if (!done && nvalid == 64) {   // rows of one group among several: 16-byte pieces without a division per element
+          flush_cfg_rows_full<T, 64, RW, MINV_LANE_TS, N * N, 64>(tile, gdst, lane);
+          done = true;
+        }
+      }
       if (!done) {
 #pragma unroll 4
         for (int g = lane; g < nvalid * RW; g += 64) {

@@ -443,4 +443,58 @@ RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid) {
   }
 }
 
+// raw-buffer descriptor of an output region (base must be wave-uniform; it is pinned in SGPRs here)
+template <class T>
+RBD_DEV __amdgpu_buffer_rsrc_t out_tile_rsrc(T* base, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
+// FULL tile of NCFG configurations: RW contiguous scalars per configuration (LDS stride TS) -> HBM (stride DST) as 16-byte
+// pieces by NT threads.  Piece g = tid + NT k of the NCFG x RV pieces is (configuration g / RV, piece g % RV); with
+// tid = RV a + b the quotient of every step follows from compile-time constants and ONE comparison -- the plain loop
+// "for (g = tid; g < nvalid * RV; g += NT) { cfg = g / RV; ... }" divides in every iteration and builds a 64-bit address
+// per store: 12-20 instructions per piece, a sixth (two-lane gradient kernel) to a half (one-lane minv kernel) of the
+// quadruped's instruction stream.  The reads of a batch are issued before its stores; the stores go through a
+// raw-buffer descriptor of the block's output region.  Caller guarantees: full tile, RW % VE == 0, DST % VE == 0, the
+// group's rows start on a 16-byte boundary, (NCFG * RV) % NT == 0.
+template <class T, int NCFG, int RW, int TS, int DST, int NT>
+RBD_DEV void flush_cfg_rows_full(const T* tile, T* gdst, int tid) {
+  constexpr int VE = 16 / (int)sizeof(T);
+  constexpr int RV = RW / VE;
+  static_assert(RW % VE == 0 && DST % VE == 0 && (NCFG * RV) % NT == 0, "flush_cfg_rows_full: shape");
+  typedef T V __attribute__((ext_vector_type(VE)));
+  typedef unsigned U4 __attribute__((ext_vector_type(4)));
+  constexpr int IT = NCFG * RV / NT;
+  constexpr int BATCH = IT < 9 ? IT : 9;
+  const __amdgpu_buffer_rsrc_t rs = out_tile_rsrc(gdst, (int)(((NCFG - 1) * DST + RW) * sizeof(T)));
+  const int a = tid / RV, bq = tid - a * RV;
+  sfor<0, (IT + BATCH - 1) / BATCH>([&](auto G_) {
+    constexpr int g0 = decltype(G_)::value * BATCH;
+    V buf[BATCH];
+    int goff[BATCH];
+    sfor<0, BATCH>([&](auto I_) {
+      constexpr int i = decltype(I_)::value, k = g0 + i;
+      if constexpr (k < IT) {
+        constexpr int qk = (NT * k) / RV, rk = (NT * k) % RV;
+        const int t = bq + rk;
+        const bool wrap = t >= RV;
+        const int cfg = a + qk + (wrap ? 1 : 0);
+        const int r = wrap ? t - RV : t;
+        if constexpr (TS % VE == 0) {
+          buf[i] = *reinterpret_cast<const V*>(tile + cfg * TS + r * VE);
+        } else {
+          sfor<0, VE>([&](auto E_) { constexpr int e = decltype(E_)::value; buf[i][e] = tile[cfg * TS + r * VE + e]; });
+        }
+        goff[i] = (cfg * DST + r * VE) * (int)sizeof(T);
+      }
+    });
+    sfor<0, BATCH>([&](auto I_) {
+      constexpr int i = decltype(I_)::value, k = g0 + i;
+      if constexpr (k < IT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, buf[i]), rs, goff[i], 0, 0);
+    });
+  });
+}
+
 }  // namespace rbdk

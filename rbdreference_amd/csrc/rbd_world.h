@@ -569,12 +569,6 @@ RBD_DEV void flush_image_rows_buf(const V* src, __amdgpu_buffer_rsrc_t rs, int v
     });
   });
 }
-template <class T>
-RBD_DEV __amdgpu_buffer_rsrc_t out_tile_rsrc(T* base, int bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-}
 
 // BATCHED = false keeps the plain loop (the fp64 workspace kernel, at 460 of 512 registers, lost 3 % with the staging).
 template <int CPI, int SST, bool BATCHED = true, class V>
