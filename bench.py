@@ -531,6 +531,36 @@ def main():
                 if isinstance(ent, dict):
                     for k in [k for k in ent if k.startswith("alg_GBps")]:
                         ent["frac" + k[len("alg_GBps"):]] = ent[k] / HBM_PEAK_GBS
+            # PMC traffic of the non-headline kernels (profiles/config_traffic.json, tools/make_config_traffic.py): attached
+            # when it was measured on these sources; traffic / algorithmic bytes per launch beside each `frac`
+            try:
+                ct = json.load(open(os.path.join(ROOT, "profiles", "config_traffic.json")))
+                if ct.get("sources_digest") == digest:
+                    kern = ct["kernels"]
+                    nvq, nbq = 18, 13                    # floating quadruped: velocities, bodies
+                    plan = {   # extra entry -> (suffix, [kernels of one call], algorithmic bytes of one call)
+                        "cfg2_atlas_minv_B16384_f32": ("", ["minv_fused_kernel<float>"], 16384 * 3720),
+                        "cfg2_atlas_rnea_cvaf_B16384_f32": ("", ["rnea_segments_kernel<float,true>"], 16384 * 2640),
+                        "atlas_rnea_grad_B16384_f32": ("", ["rnea_grad_tree_kernel<float,true>"], 16384 * (4 * 30 + 2 * 900) * 4),
+                        "atlas_rnea_grad_B16384_f64": ("", ["rnea_grad_tree_ws_kernel<double,true>"], 16384 * (4 * 30 + 2 * 900) * 8),
+                        "cfg4_quadruped_rnea_grad+minv_B65536_f64": ("", ["rnea_grad_kernel<double,true,false>", "minv_lane_kernel<double>"], 65536 * 3840),
+                    }
+                    fbq = {"_rnea": (["rnea_fbw_kernel<float,true,0>"], 65536 * (4 * nvq + 18 * nbq) * 4),
+                           "_minv": (["minv_fbm_kernel<float>"], 65536 * (nvq + nvq * nvq) * 4),
+                           "_rnea_grad": (["rnea_grad_fbw_kernel<float,true>"], 65536 * (4 * nvq + 2 * nvq * nvq) * 4)}
+                    for key, (sfx, ks, alg) in plan.items():
+                        if key in extra and all(k in kern for k in ks):
+                            tb = sum(kern[k][0]["hbm_bytes_per_launch"] for k in ks)
+                            extra[key]["traffic_bytes_per_call" + sfx] = tb
+                            extra[key]["traffic_over_algorithmic" + sfx] = tb / alg
+                    if "floating_quadruped_B65536_f32" in extra:
+                        for sfx, (ks, alg) in fbq.items():
+                            if all(k in kern for k in ks):
+                                tb = sum(kern[k][0]["hbm_bytes_per_launch"] for k in ks)
+                                extra["floating_quadruped_B65536_f32"]["traffic_over_algorithmic" + sfx] = tb / alg
+                    extra["traffic_note"] = ct.get("note")
+            except Exception as e:
+                extra["traffic_error"] = repr(e)
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(robot, 3)
