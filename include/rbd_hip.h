@@ -13,12 +13,16 @@
  *     the caller owns all buffers; nothing is allocated per call -- with ONE exception: rbd_rnea_grad_f64 /
  *     rbd_rnea_with_grad_f64 of a tree too big for registers and LDS (the 30-body humanoid; rbd_kernel_name says
  *     rnea_grad_tree_ws_kernel) keeps a LIBRARY-OWNED scratch buffer per (device, stream), sized by what is resident
- *     at once, not by B (126 MB for that robot): allocated (hipMalloc) by the first such call on a stream, reused by
- *     every later one, never freed.  Make one such call on a stream before capturing calls on it into a hipGraph;
- *     calls on different streams use different buffers, calls on one stream are ordered and share one;
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous; the
- *     calling thread's CURRENT device must be the stream's device (as for any HIP launch): per-kernel
- *     launch attributes and grid sizes are cached per current device;
+ *     at once, not by B (126 MB for that robot): allocated (hipMalloc) by the first such call on a stream and reused by
+ *     every later one.  A buffer that was handed out is never freed or moved by a later call (launches in flight,
+ *     bound launches and captured graphs may hold its address); rbd_release_workspaces() frees them all.  GRAPH
+ *     CAPTURE: make one such call on a stream before capturing calls on it into a hipGraph (hipMalloc is not
+ *     capturable), and do not call rbd_release_workspaces() while such a graph may still be launched.  Calls on
+ *     different streams use different buffers, calls on one stream are ordered and share one;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream of the calling thread's current device);
+ *     launches are asynchronous; every entry point runs on the STREAM's device (it switches the calling thread's
+ *     current device for the duration of the call if that is another one), and per-kernel launch attributes, grid
+ *     sizes and the library-owned workspace are cached per that device;
  *   - return 0 on success, <0 for argument errors (RBD_ERR_*), >0 = hipError_t of a failed launch;
  *     rbd_last_error() returns a thread-local message for the last non-zero return;
  *   - no C++ exceptions cross this boundary; the model is immutable, so concurrent calls from
@@ -71,6 +75,10 @@ typedef struct rbd_model_info {
 
 int rbd_abi_version(void);
 const char* rbd_last_error(void);
+/* Frees every library-owned workspace (see "Conventions").  Synchronises each device that holds one first.  The caller
+ * guarantees that no call into this library is in flight on another thread and that no captured graph containing one
+ * of its launches will be replayed.  Returns 0, or the hipError_t of a failed synchronisation. */
+int rbd_release_workspaces(void);
 /* The robot this library was compiled for (host-side, no GPU needed). */
 int rbd_model_info(rbd_model_info_t* out);
 

@@ -182,6 +182,10 @@ def main():
     # one root, a two-body stem and three four-body limbs under its second body (segment-wave kernels)
     robots.append(("random_limbs_n14", random_tree([-1, 0, 1, 2, 3, 4, 1, 6, 7, 8, 1, 10, 11, 12], seed=41,
                                                     name="random_limbs_n14"), 205))
+    # two independent nine-body chains: a multi-root robot too deep / big for the register plans, i.e. the fp64 workspace
+    # tree kernel on its single-wave (one block per root) layout (the blocks of the two roots shared a region)
+    robots.append(("random_twochains_n18", random_tree([-1, 0, 1, 2, 3, 4, 5, 6, 7, -1, 9, 10, 11, 12, 13, 14, 15, 16], seed=57,
+                                                        name="random_twochains_n18"), 206))
     only = set(sys.argv[1:])
     for nm, robot, seed in fb_robots():
         if only and nm not in only:
@@ -198,7 +202,7 @@ def main():
         robots = [r for r in robots if r[0] in only]
     for nm, robot, seed in robots:
         n = robot.get_num_bodies()
-        S = N_SAMPLES if n <= 12 else 8
+        S = N_SAMPLES if n <= 12 else (8 if n != 18 else 4)
         q, qd, qdd = sample_inputs(n, seed, S)
         data = run_reference(robot, q, qd, qdd)
         data.update(q=q, qd=qd, qdd=qdd, seed=np.int64(seed),

@@ -24,7 +24,7 @@ RBD_OP_RNEA, RBD_OP_RNEA_GRAD, RBD_OP_MINV = 0, 1, 2
 
 # every symbol include/rbd_hip.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "rbd_abi_version", "rbd_last_error", "rbd_model_info",
+    "rbd_abi_version", "rbd_last_error", "rbd_model_info", "rbd_release_workspaces",
     "rbd_set_option", "rbd_get_option", "rbd_kernel_name",
     "rbd_rnea_f32", "rbd_rnea_f64", "rbd_rnea_grad_f32", "rbd_rnea_grad_f64",
     "rbd_rnea_with_grad_f32", "rbd_rnea_with_grad_f64",
@@ -62,6 +62,8 @@ def _declare(lib):
     lib.rbd_last_error.argtypes = []
     lib.rbd_model_info.restype = c_int
     lib.rbd_model_info.argtypes = [POINTER(RbdModelInfo)]
+    lib.rbd_release_workspaces.restype = c_int
+    lib.rbd_release_workspaces.argtypes = []
     lib.rbd_set_option.restype = c_int
     lib.rbd_set_option.argtypes = [c_int, c_int]
     lib.rbd_get_option.restype = c_int
@@ -145,6 +147,7 @@ class RbdLibrary:
         self._bg = None
         self._bg_err = None
         self._opts = {}
+        self.epoch = 0                          # bumped by set_option: cached launch plans (api.py) are per epoch
         self._lock = threading.RLock()
         self._tls = threading.local()
         if lazy is None:
@@ -290,6 +293,14 @@ class RbdLibrary:
         self._tls.lib = lib
         return getattr(lib, f"{base}_{sfx}" if sfx else base)
 
+    def resolve(self, base: str, sfx: str, has_qdd: bool = True):
+        """The library object that answers ``base`` NOW, resolved ONCE: a call that needs several things of it (the
+        workspace size AND the entry point) must take them from this one object -- if the background build finishes
+        between two separate look-ups, the size would come from one library and the launch from another."""
+        lib = self.serving(base, sfx, has_qdd)
+        self._tls.lib = lib
+        return lib
+
     def served_by_generic(self) -> bool:
         """True if the calling thread's last ``fn()`` / ``serving()`` answer was the model-handle library."""
         return bool(getattr(getattr(self._tls, "lib", None), "is_generic", False))
@@ -311,6 +322,13 @@ class RbdLibrary:
                 self._tls.lib = lib
                 self.check(lib.rbd_set_option(option, value))
             self._opts[option] = value
+            self.epoch += 1
+
+    @property
+    def stable(self) -> bool:
+        """True once the robot's own FULL library is loaded: from then on every entry point resolves to the same
+        function object for good (api.py caches its launch plans only in this state)."""
+        return self._full is not None
 
     def get_option(self, option: int) -> int:
         with self._lock:

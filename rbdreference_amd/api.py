@@ -11,6 +11,9 @@ library every call raises.
 from __future__ import annotations
 
 import contextlib
+import os
+import threading
+from sys import getrefcount as _refs
 from typing import Optional
 
 import numpy as np
@@ -20,6 +23,71 @@ from ._lib import RbdLibrary
 from .packer import PackedModel, pack_robot
 
 __all__ = ["RBDReference", "BoundLaunch"]
+
+_T = torch.Tensor
+_F32, _F64 = torch.float32, torch.float64
+_storage_uses = getattr(torch._C, "_storage_Use_Count", None)          # holders of a StorageImpl (views, detached aliases)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # hipStream_t of torch's current stream, as an int
+_cur_dev = torch.cuda.current_device
+_tid = threading.get_ident
+
+# ---- one-shot calls without per-call allocations --------------------------------------------
+# A method call used to cost 7-14 us of Python around an 11-25 us kernel: shape checks, a device guard, a stream
+# look-up and one torch.empty per output.  The second call with the same signature (op, B, dtype, device, stream)
+# is now: validate three tensors by attribute, take a FREE output set from a small pool, ONE ctypes call.
+# "Free" keeps the reference's contract that every call returns fresh outputs (RBDReference.py:623, :785, :1345):
+# a set is handed out again only when the caller holds neither its tensors (Python reference counts) nor any view or
+# alias of their storage (StorageImpl use count) any more; while anything is still held, another set is used (up to
+# POOL_SETS per signature, then a new one replaces the oldest -- which stays valid for whoever holds it).  Big outputs
+# (> POOL_MAX_BYTES per set) are never pooled: there the kernel dwarfs the Python.  RBD_OUTPUT_POOL=0 turns it off.
+POOL_SETS = 3
+POOL_MAX_BYTES = 160 << 20
+POOL_SIGNATURES = 16
+
+
+class _OutSet:
+    __slots__ = ("flat", "outs", "ptrs", "cdata", "base")
+
+    def __init__(self, shapes, dt, dev):
+        esz = 4 if dt is _F32 else 8
+        sizes = [(int(np.prod(sh)) * esz + 15) & ~15 for sh in shapes]
+        self.flat = torch.empty((sum(sizes),), device=dev, dtype=torch.uint8)
+        outs, off = [], 0
+        for sh, nb in zip(shapes, sizes):
+            outs.append(self.flat[off:off + int(np.prod(sh)) * esz].view(dt).view(sh))
+            off += nb
+        self.outs = tuple(outs)
+        del outs
+        self.ptrs = tuple(t.data_ptr() for t in self.outs)
+        self.cdata = self.flat.untyped_storage()._cdata
+        self.base = None
+        self.base = self._probe()
+
+    def _probe(self):
+        return (_storage_uses(self.cdata), _refs(self.outs), *[_refs(t) for t in self.outs])
+
+    def free(self):
+        return self._probe() == self.base
+
+
+class _Plan:
+    """Everything of a call signature that does not change between calls."""
+    __slots__ = ("fn", "sets", "epoch", "ws", "wsp", "wsb", "shapes", "dt", "dev")
+
+    def __init__(self, fn, shapes, dt, dev, epoch, ws=None, wsb=0):
+        self.fn, self.shapes, self.dt, self.dev, self.epoch = fn, shapes, dt, dev, epoch
+        self.ws, self.wsb, self.wsp = ws, wsb, (ws.data_ptr() if ws is not None else None)
+        self.sets = []
+
+    def take(self):
+        for s in self.sets:
+            if s.free():
+                return s
+        s = _OutSet(self.shapes, self.dt, self.dev)
+        if len(self.sets) >= POOL_SETS:
+            self.sets.pop(0)
+        self.sets.append(s)
+        return s
 
 
 class BoundLaunch:
@@ -52,6 +120,61 @@ class RBDReference:
         self._lib = RbdLibrary(self.model, build=build, generic=generic)
         self.n = self.model.n            # bodies
         self.nv = self.model.nv          # columns of q, qd, qdd, c: n, or n + 5 with a floating base
+        self._plans = {}
+        self._pool_on = (os.environ.get("RBD_OUTPUT_POOL", "1") != "0" and _storage_uses is not None and _raw_stream is not None)
+
+    # ---- cached launch plans (see the note at the top of the module) ---------------------------------------------
+    def _sig(self, q, qd, qdd):
+        """``(B, dtype, device index, raw stream)`` when q, qd (qdd unless None) are plain contiguous ``[B, nv]`` tensors of one
+        dtype on one GPU and the robot's own library is loaded; None sends the call down the general path."""
+        if not self._pool_on or type(q) is not _T or self._lib._full is None:
+            return None
+        dt = q.dtype
+        if dt is not _F32 and dt is not _F64:
+            return None
+        idx = q.get_device()
+        shp = q.shape
+        if idx < 0 or len(shp) != 2 or shp[1] != self.nv or shp[0] == 0 or not q.is_contiguous():
+            return None
+        if qd is not None and (type(qd) is not _T or qd.dtype is not dt or qd.get_device() != idx or qd.shape != shp or not qd.is_contiguous()):
+            return None
+        if qdd is not None and (type(qdd) is not _T or qdd.dtype is not dt or qdd.get_device() != idx or qdd.shape != shp or not qdd.is_contiguous()):
+            return None
+        st = _raw_stream(idx)
+        if st == 0 and _cur_dev() != idx:       # the null stream belongs to the CURRENT device (include/rbd_hip.h)
+            return None
+        return shp[0], dt, idx, st
+
+    def _plan(self, key, make):
+        key = (_tid(), key)                     # one pool per host thread: a set is "free" by reference counts, which another
+        p = self._plans.get(key)                # thread could not tell from "handed out a moment ago, not yet bound"
+        if p is None or p.epoch != self._lib.epoch:
+            p = make()
+            if p is None:
+                return None
+            if len(self._plans) >= POOL_SIGNATURES:
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = p
+        return p
+
+    def _mk_plan(self, base, dt, idx, shapes, has_qdd=True, ws_query=None):
+        """A `_Plan` for entry point ``base``: function object, output shapes, and -- resolved from the SAME library object
+        -- the scratch the entry point needs (``ws_query(lib, esz) -> bytes``)."""
+        esz = 4 if dt is _F32 else 8
+        if sum(int(np.prod(sh)) for sh in shapes) * esz > POOL_MAX_BYTES:
+            return None
+        dev = torch.device("cuda", idx)
+        sfx = "f32" if esz == 4 else "f64"
+        lib = self._lib.resolve(base, sfx, has_qdd)
+        ws, wsb = None, 0
+        if ws_query is not None:
+            wsb = int(ws_query(lib, esz))
+            ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
+        return _Plan(getattr(lib, f"{base}_{sfx}"), shapes, dt, dev, self._lib.epoch, ws, wsb)
+
+    def release_pools(self):
+        """Drop the cached launch plans and their pooled output sets (tensors the caller still holds stay valid)."""
+        self._plans.clear()
 
     @contextlib.contextmanager
     def shard_of(self, global_rows: int):
@@ -113,13 +236,10 @@ class RBDReference:
         return out, unb, is_np, dev, dt
 
     def _minv_ws(self, B: int, esz: int) -> int:
-        """rbd_minv_workspace_bytes from the library that will serve the rbd_minv call of that precision."""
+        """rbd_minv_workspace_bytes from the library that serves rbd_minv of that precision right now (a QUERY for
+        callers who bring their own scratch; the methods themselves resolve the library once per call)."""
         lib = self._lib.serving("rbd_minv", "f32" if esz == 4 else "f64")
         return int(lib.rbd_minv_workspace_bytes(B, esz))
-
-    def _fd_ws(self, B: int, esz: int) -> int:
-        lib = self._lib.serving("rbd_forward_dynamics", "f32" if esz == 4 else "f64")
-        return int(lib.rbd_fd_workspace_bytes(B, esz))
 
     @staticmethod
     def _ptr(t: Optional[torch.Tensor]):
@@ -148,6 +268,17 @@ class RBDReference:
         ``outputs="c"`` skips v, a, f (returns ``(c, None, None, None)``).  ``out=(c, v, a, f)``: write into these
         pre-allocated device tensors (batched tensor inputs only) -- a loop that owns its buffers then pays the
         launch alone, not four allocations per call."""
+        if out is None and outputs == "cvaf":
+            sg = self._sig(q, qd, qdd)
+            if sg is not None:
+                B, dt, idx, st = sg
+                p = self._plan(("rnea", B, dt, idx, st), lambda: self._mk_plan("rbd_rnea", dt, idx, ((B, self.nv), (B, 6, self.n), (B, 6, self.n), (B, 6, self.n))))
+                if p is not None:
+                    o = p.take()
+                    rc = p.fn(q.data_ptr(), qd.data_ptr(), None if qdd is None else qdd.data_ptr(), float(GRAVITY), B, *o.ptrs, st)
+                    if rc != 0:
+                        self._lib.check(rc)
+                    return o.outs
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         if out is not None:
@@ -363,6 +494,20 @@ class RBDReference:
         reference computes internally (``:1353``) -> ``(c, dc_du)``.  Floating base: ``n = NB + 5`` and the
         base's six position columns are derivatives along a base-frame twist, as in the reference; robots
         with fewer than six bodies are refused (the reference raises IndexError for them, ``:1168``)."""
+        if out is None:
+            sg = self._sig(q, qd, qdd)
+            if sg is not None:
+                B, dt, idx, st = sg
+                hq = qdd is not None
+                p = self._plan(("rnea_grad", B, dt, idx, st, hq, return_c),
+                               lambda: self._mk_plan("rbd_rnea_grad", dt, idx, ((B, self.nv), (B, self.nv, 2 * self.nv)) if return_c else ((B, self.nv, 2 * self.nv),), hq))
+                if p is not None:
+                    o = p.take()
+                    rc = p.fn(q.data_ptr(), qd.data_ptr(), qdd.data_ptr() if hq else None, float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B,
+                              o.ptrs[0] if return_c else None, o.ptrs[-1], st)
+                    if rc != 0:
+                        self._lib.check(rc)
+                    return o.outs if return_c else o.outs[0]
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         if out is not None:      # out=dc_du, or out=(c, dc_du) with return_c=True: pre-allocated device tensors
@@ -391,6 +536,17 @@ class RBDReference:
         """``rnea`` and ``rnea_grad`` of the same inputs in one call -> ``(c, v, a, f, dc_du)``: what the
         reference computes inside ``rnea_grad`` (``RBDReference.py:1353`` runs ``rnea`` and drops its
         outputs).  For small batches this is one launch of the column kernel."""
+        sg = self._sig(q, qd, qdd)
+        if sg is not None:
+            B, dt, idx, st = sg
+            p = self._plan(("rnea_and_grad", B, dt, idx, st), lambda: self._mk_plan(
+                "rbd_rnea_with_grad", dt, idx, ((B, self.nv), (B, 6, self.n), (B, 6, self.n), (B, 6, self.n), (B, self.nv, 2 * self.nv))))
+            if p is not None:
+                o = p.take()
+                rc = p.fn(q.data_ptr(), qd.data_ptr(), None if qdd is None else qdd.data_ptr(), float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B, *o.ptrs, st)
+                if rc != 0:
+                    self._lib.check(rc)
+                return o.outs
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         with torch.cuda.device(dev):
@@ -411,6 +567,18 @@ class RBDReference:
         reference leaves forward-pass by-products there, ``:771``).  ``out=`` / ``workspace=``: a pre-allocated
         ``[B, n, n]`` result tensor and a uint8 scratch tensor of ``minv_workspace_bytes(B, dtype)`` bytes
         (batched tensor input only), for loops that own their buffers."""
+        if out is None and workspace is None:
+            sg = self._sig(q, None, None)
+            if sg is not None:
+                B, dt, idx, st = sg
+                p = self._plan(("minv", B, dt, idx, st), lambda: self._mk_plan(
+                    "rbd_minv", dt, idx, ((B, self.nv, self.nv),), ws_query=lambda lib, esz: lib.rbd_minv_workspace_bytes(B, esz)))
+                if p is not None:
+                    o = p.take()
+                    rc = p.fn(q.data_ptr(), B, 1 if output_dense else 0, o.ptrs[0], p.wsp if p.wsb else None, p.wsb, st)
+                    if rc != 0:
+                        self._lib.check(rc)
+                    return o.outs[0]
         (q,), unb, is_np, dev, dt = self._prep(q)
         B = q.shape[0]
         esz = 4 if dt == torch.float32 else 8
@@ -419,7 +587,9 @@ class RBDReference:
         with torch.cuda.device(dev):
             M = torch.empty((B, self.nv, self.nv), device=dev, dtype=dt) if out is None else \
                 self._check_out(out, (B, self.nv, self.nv), dev, dt, "Minv")
-            wsb = self._minv_ws(B, esz)
+            sfx = "f32" if esz == 4 else "f64"
+            lib = self._lib.resolve("rbd_minv", sfx)            # ONE resolution: size and entry point from the same library
+            wsb = int(lib.rbd_minv_workspace_bytes(B, esz))
             if workspace is not None:
                 if workspace.dtype != torch.uint8 or workspace.device != dev or workspace.numel() < wsb or not workspace.is_contiguous():
                     raise ValueError(f"workspace: a contiguous uint8 tensor of >= {wsb} bytes on {dev}")
@@ -427,7 +597,7 @@ class RBDReference:
             else:
                 ws = torch.empty((wsb,), device=dev, dtype=torch.uint8) if wsb > 0 else None   # most robots: no scratch at all
             st = torch.cuda.current_stream(dev).cuda_stream
-            self._lib.check(self._fn("rbd_minv", dt)(
+            self._lib.check(getattr(lib, f"rbd_minv_{sfx}")(
                 self._ptr(q), B, 1 if output_dense else 0, self._ptr(M), ws.data_ptr() if ws is not None else None, wsb, st))
         return self._ret(M, unb, is_np)
 
@@ -468,9 +638,10 @@ class RBDReference:
                 args = lambda st: (p[0], p[1], p[2], g, damp, B, *[o.data_ptr() for o in outs], st)   # noqa: E731
             elif op == "minv":
                 outs = (E(B, self.nv, self.nv),)
-                wsb = self._minv_ws(B, esz)
+                lib = self._lib.resolve("rbd_minv", "f32" if esz == 4 else "f64")
+                wsb = int(lib.rbd_minv_workspace_bytes(B, esz))
                 ws = torch.empty((wsb,), device=dev, dtype=torch.uint8) if wsb > 0 else None
-                fn = self._fn("rbd_minv", dt)
+                fn = getattr(lib, "rbd_minv_f32" if esz == 4 else "rbd_minv_f64")
                 wp = ws.data_ptr() if ws is not None else None
                 args = lambda st: (p[0], B, 1 if output_dense else 0, outs[0].data_ptr(), wp, wsb, st)   # noqa: E731
                 outs = outs + ((ws,) if ws is not None else ())      # (kept alive with the launch; not a result)
@@ -508,29 +679,45 @@ class RBDReference:
         return self._ret(qdd, unb, is_np)
 
     def _fd(self, q, qd, u, GRAVITY, want_grad):
+        sg = self._sig(q, qd, u) if u is not None else None
+        if sg is not None:
+            B, dt, idx, st = sg
+            base = "rbd_forward_dynamics_grad" if want_grad else "rbd_forward_dynamics"
+            shapes = ((B, self.nv), (B, self.nv, 2 * self.nv)) if want_grad else ((B, self.nv),)
+            p = self._plan((base, B, dt, idx, st), lambda: self._mk_plan(base, dt, idx, shapes, ws_query=lambda lib, esz: lib.rbd_fd_workspace_bytes(B, esz)))
+            if p is not None:
+                o = p.take()
+                if want_grad:
+                    rc = p.fn(q.data_ptr(), qd.data_ptr(), u.data_ptr(), float(GRAVITY), B, o.ptrs[0], o.ptrs[1], p.wsp, p.wsb, st)
+                else:
+                    rc = p.fn(q.data_ptr(), qd.data_ptr(), u.data_ptr(), float(GRAVITY), B, o.ptrs[0], p.wsp, p.wsb, st)
+                if rc != 0:
+                    self._lib.check(rc)
+                return o.outs[0], (o.outs[1] if want_grad else None), False, False
         (q, qd, u), unb, is_np, dev, dt = self._prep(q, qd, u)
         B = q.shape[0]
         esz = 4 if dt == torch.float32 else 8
+        sfx = "f32" if esz == 4 else "f64"
         with torch.cuda.device(dev):
             qdd = torch.empty((B, self.nv), device=dev, dtype=dt)
             st = torch.cuda.current_stream(dev).cuda_stream
-            generic = getattr(self._lib.serving("rbd_forward_dynamics", "f32" if esz == 4 else "f64"), "is_generic", False)
+            base = "rbd_forward_dynamics_grad" if want_grad else "rbd_forward_dynamics"
+            lib = self._lib.resolve(base, sfx)              # ONE resolution: workspace size, branch and entry point from the same library
+            generic = getattr(lib, "is_generic", False)
+            fn = getattr(lib, f"{base}_{sfx}")
             if not want_grad and (self.model.floating or generic):   # rnea (bias force) + minv + one product: scratch for c and Minv
-                wsb = int(self._fd_ws(B, esz))
+                wsb = int(lib.rbd_fd_workspace_bytes(B, esz))
                 ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
-                self._lib.check(self._fn("rbd_forward_dynamics", dt)(
-                    self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), ws.data_ptr(), wsb, st))
+                self._lib.check(fn(self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), ws.data_ptr(), wsb, st))
                 return qdd, None, unb, is_np
             if not want_grad:        # one articulated-body launch, no scratch
-                self._lib.check(self._fn("rbd_forward_dynamics", dt)(
-                    self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), None, 0, st))
+                self._lib.check(fn(self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd), None, 0, st))
                 return qdd, None, unb, is_np
-            wsb = int(self._fd_ws(B, esz))
+            wsb = int(lib.rbd_fd_workspace_bytes(B, esz))
             ws = torch.empty((max(wsb, 1),), device=dev, dtype=torch.uint8)
             d = torch.empty((B, self.nv, 2 * self.nv), device=dev, dtype=dt)
-            self._lib.check(self._fn("rbd_forward_dynamics_grad", dt)(
-                self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
-                self._ptr(d), ws.data_ptr(), wsb, st))
+            self._lib.check(fn(self._ptr(q), self._ptr(qd), self._ptr(u), float(GRAVITY), B, self._ptr(qdd),
+                               self._ptr(d), ws.data_ptr(), wsb, st))
             return qdd, d, unb, is_np
 
     def forward_dynamics(self, q, qd, u, GRAVITY=-9.81):

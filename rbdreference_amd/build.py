@@ -141,7 +141,7 @@ def _up_to_date(out: str, digest: str) -> bool:
 
 
 def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
-                extra_flags: Optional[list] = None, tag: str = "") -> str:
+                extra_flags: Optional[list] = None, tag: str = "", link_flags: Optional[list] = None) -> str:
     """Compile the library for packed model `m` (no-op when an up-to-date one exists).  The single
     source file is compiled as several translation units in parallel (-DRBD_TU_*) and linked.
     Safe across processes: the whole check/build/publish sequence holds an exclusive file lock, and
@@ -159,10 +159,37 @@ def build_model(m: PackedModel, force: bool = False, verbose: bool = False,
     with _BuildLock(out):
         if not force and _up_to_date(out, digest):     # another process finished it while we waited
             return out
-        return _build_locked(m, out, flags, digest, force, verbose)
+        return _build_locked(m, out, flags, digest, force, verbose, list(link_flags or []))
 
 
-def _build_locked(m, out, flags, digest, force, verbose) -> str:
+# Host-side sanitizer build (SURVEY.md section 5 "Race detection / sanitizers"): the C-ABI's host code
+# -- argument / alignment / workspace checks, the option atomics, the workspace pool, the per-device caches -- compiled
+# with AddressSanitizer + UndefinedBehaviorSanitizer (HOST side only: -Xarch_host; GPU sanitizers are not available on
+# this pool).  tests/test_host_logic.py loads it in a child process with the sanitizer runtime preloaded and runs the
+# no-GPU checks against it.
+SANITIZE_COMPILE = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-sanitize=vptr",
+                    "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-fno-sanitize-recover=undefined"]
+SANITIZE_LINK = ["-fsanitize=address,undefined", "-fno-sanitize=vptr", "-shared-libsan"]
+
+
+def sanitizer_runtime() -> str:
+    """Path of the shared ASan runtime of hipcc's clang (LD_PRELOAD it into the process that dlopens the library)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc_path())), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    r = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    if r.returncode != 0 or not os.path.isabs(p) or not os.path.exists(p):
+        raise RuntimeError("the host AddressSanitizer runtime of hipcc's clang was not found")
+    return p
+
+
+def build_sanitized(m: PackedModel, verbose: bool = False) -> str:
+    """The library of packed model `m` with its HOST code under ASan + UBSan: ``librbd_<name>_<hash>.asan.so``."""
+    return build_model(m, verbose=verbose, extra_flags=SANITIZE_COMPILE, tag="asan", link_flags=SANITIZE_LINK)
+
+
+def _build_locked(m, out, flags, digest, force, verbose, link_flags=()) -> str:
     from concurrent.futures import ThreadPoolExecutor
     uniq = f"{os.getpid()}.{threading.get_ident()}"
     hdr = header_path(m)
@@ -209,7 +236,7 @@ def _build_locked(m, out, flags, digest, force, verbose) -> str:
     with ThreadPoolExecutor(max_workers=len(units)) as ex:
         objs = list(ex.map(compile_tu, units))
     link_tmp = f"{out}.{uniq}.tmp"
-    _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", link_tmp],
+    _run([hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *link_flags, *objs, "-o", link_tmp],
          f"{m.name} link", 2e9)
     os.replace(link_tmp, out)
     stamp_tmp = f"{out}.stamp.{uniq}.tmp"
@@ -338,7 +365,7 @@ def generic_lib_path() -> str:
 def _generic_digest() -> str:
     import hashlib
     h = hashlib.sha256()
-    for f in (GENERIC_SRC, os.path.join(os.path.dirname(HERE), "include", "rbd_generic.h")):
+    for f in (GENERIC_SRC, os.path.join(os.path.dirname(HERE), "include", "rbd_generic.h"), os.path.join(CSRC, "rbd_sincos.h")):
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(GENERIC_FLAGS).encode())

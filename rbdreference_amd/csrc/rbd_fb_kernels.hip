@@ -11,6 +11,7 @@
 #include "rbd_fb_passes.h"
 #include "rbd_fb_minv.h"
 #include "../../include/rbd_hip.h"
+#include "rbd_host.h"
 #include <cstdio>
 #include <cstring>
 #include <atomic>
@@ -351,51 +352,51 @@ __attribute__((visibility("hidden"))) int rbd_minv_needs_ws_f64(void);
     return 0;                                                                                                               \
   }                                                                                                                         \
   int rbd_rnea_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* c, T* v, T* a, T* f, void* stream) {   \
-    return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \
+    RbdStreamDevice sd_(stream); return rnea_fb_launch<T>(q, qd, qdd, gravity, B, c, v, a, f, stream);                                                   \
   }                                                                                                                         \
   int rbd_minv_##SFX(const T* q, int64_t B, int output_dense, T* Minv, void*, size_t, void* stream) {                       \
-    return minv_fb_launch<T>(q, B, output_dense, Minv, stream);                                                             \
+    RbdStreamDevice sd_(stream); return minv_fb_launch<T>(q, B, output_dense, Minv, stream);                                                             \
   }                                                                                                                         \
   int rbd_forward_dynamics_##SFX(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, void* ws, size_t wsb,   \
                                  void* stream) {                                                                            \
-    return fd_fb_launch<T>(q, qd, u, gravity, B, qdd, ws, wsb, stream);                                                     \
+    RbdStreamDevice sd_(stream); return fd_fb_launch<T>(q, qd, u, gravity, B, qdd, ws, wsb, stream);                                                     \
   }                                                                                                                         \
   int rbd_rnea_fpass_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int64_t B, T* v, T* a, T* f, void* stream) {   \
-    return rnea_pass_fb_launch<T>(1, q, qd, qdd, gravity, B, nullptr, v, a, f, stream);                                     \
+    RbdStreamDevice sd_(stream); return rnea_pass_fb_launch<T>(1, q, qd, qdd, gravity, B, nullptr, v, a, f, stream);                                     \
   }                                                                                                                         \
   int rbd_rnea_bpass_##SFX(const T* q, T* f, int64_t B, T* c, void* stream) {                                               \
-    return rnea_pass_fb_launch<T>(2, q, nullptr, nullptr, T(0), B, c, nullptr, nullptr, f, stream);                         \
+    RbdStreamDevice sd_(stream); return rnea_pass_fb_launch<T>(2, q, nullptr, nullptr, T(0), B, c, nullptr, nullptr, f, stream);                         \
   }                                                                                                                         \
   int rbd_rnea_grad_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* dc_du, void* stream) { \
-    return grad_fb_launch<T>("rbd_rnea_grad", q, qd, qdd, gravity, use_damping, B, c, nullptr, nullptr, nullptr, dc_du, stream); \
+    RbdStreamDevice sd_(stream); return grad_fb_launch<T>("rbd_rnea_grad", q, qd, qdd, gravity, use_damping, B, c, nullptr, nullptr, nullptr, dc_du, stream); \
   }                                                                                                                         \
   int rbd_rnea_with_grad_##SFX(const T* q, const T* qd, const T* qdd, T gravity, int use_damping, int64_t B, T* c, T* v, T* a, T* f, \
                                T* dc_du, void* stream) {                                                                    \
-    return grad_fb_launch<T>("rbd_rnea_with_grad", q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);          \
+    RbdStreamDevice sd_(stream); return grad_fb_launch<T>("rbd_rnea_with_grad", q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);          \
   }                                                                                                                         \
   int rbd_rnea_grad_fpass_dq_##SFX(const T* q, const T* qd, const T* v, const T* a, T gravity, int64_t B, T* dv, T* da, T* df, void* stream) { \
-    return grad_fpass_fb_launch<T, false>(q, qd, v, a, gravity, B, dv, da, df, stream);                                     \
+    RbdStreamDevice sd_(stream); return grad_fpass_fb_launch<T, false>(q, qd, v, a, gravity, B, dv, da, df, stream);                                     \
   }                                                                                                                         \
   int rbd_rnea_grad_fpass_dqd_##SFX(const T* q, const T* qd, const T* v, int64_t B, T* dv, T* da, T* df, void* stream) {    \
-    return grad_fpass_fb_launch<T, true>(q, qd, v, nullptr, T(0), B, dv, da, df, stream);                                   \
+    RbdStreamDevice sd_(stream); return grad_fpass_fb_launch<T, true>(q, qd, v, nullptr, T(0), B, dv, da, df, stream);                                   \
   }                                                                                                                         \
   int rbd_rnea_grad_bpass_dq_##SFX(const T* q, const T* f, T* df, int64_t B, T* dc, void* stream) {                         \
-    return grad_bpass_fb_launch<T, false>(q, f, df, 0, B, dc, stream);                                                      \
+    RbdStreamDevice sd_(stream); return grad_bpass_fb_launch<T, false>(q, f, df, 0, B, dc, stream);                                                      \
   }                                                                                                                         \
   int rbd_rnea_grad_bpass_dqd_##SFX(const T* q, T* df, int use_damping, int64_t B, T* dc, void* stream) {                   \
-    return grad_bpass_fb_launch<T, true>(q, nullptr, df, use_damping, B, dc, stream);                                       \
+    RbdStreamDevice sd_(stream); return grad_bpass_fb_launch<T, true>(q, nullptr, df, use_damping, B, dc, stream);                                       \
   }                                                                                                                         \
   int rbd_minv_bpass_##SFX(const T* q, int64_t B, T* Minv, T* F, T* U, T* Dinv, void* stream) {                             \
-    return minv_bpass_fb_launch<T>(q, B, Minv, F, U, Dinv, stream);                                                         \
+    RbdStreamDevice sd_(stream); return minv_bpass_fb_launch<T>(q, B, Minv, F, U, Dinv, stream);                                                         \
   }                                                                                                                         \
   int rbd_minv_fpass_##SFX(const T* q, int64_t B, T* Minv, T* F, const T* U, const T* Dinv, void* stream) {                 \
-    return minv_fpass_fb_launch<T>(q, B, Minv, F, U, Dinv, stream);                                                         \
+    RbdStreamDevice sd_(stream); return minv_fpass_fb_launch<T>(q, B, Minv, F, U, Dinv, stream);                                                         \
   }                                                                                                                         \
   int rbd_crba_##SFX(const T*, int64_t, T*, void*) { return unsupported("rbd_crba"); }                                      \
   int rbd_aba_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*) { return unsupported("rbd_aba"); }                 \
   int rbd_forward_dynamics_grad_##SFX(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd, T* dqdd_du, void* ws, \
                                       size_t wsb, void* stream) {                                                           \
-    return fdg_fb_launch<T>(q, qd, u, gravity, B, qdd, dqdd_du, ws, wsb, stream);                                           \
+    RbdStreamDevice sd_(stream); return fdg_fb_launch<T>(q, qd, u, gravity, B, qdd, dqdd_du, ws, wsb, stream);                                           \
   }
 
 #ifdef RBD_TU_FB_F32

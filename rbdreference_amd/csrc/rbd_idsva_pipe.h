@@ -122,13 +122,13 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
     sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; qv[j] = qn[j]; qdv[j] = qdn[j]; qddv[j] = qddn[j]; });
   };
   // sin / cos of bodies [J0, J1): ONE wave-uniform branch for the chunk (any lane, any joint beyond the range of
-  // the fast reduction -> the library routine for the chunk) instead of a lane-masked branch per joint
+  // the fast reduction or non-finite -> the branch-free wide routine of rbd_sincos.h for the chunk)
   auto trig_chunk = [&](auto J0_, auto J1_) {
     constexpr int J0 = decltype(J0_)::value, J1 = decltype(J1_)::value;
     T mx = T(0);
     sfor<J0, J1>([&](auto J) { constexpr int j = decltype(J)::value; mx = __builtin_fmaxf(mx, __builtin_fabsf(qv[j])); });
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(mx <= 8192.0f)) != 0, 0)) {
-      sfor<J0, J1>([&](auto J) { constexpr int j = decltype(J)::value; sincosf(qv[j], &tr[j].s, &tr[j].c); });
+      sfor<J0, J1>([&](auto J) { constexpr int j = decltype(J)::value; sincos_wide_(qv[j], &tr[j].s, &tr[j].c); });
     } else {
       sfor<J0, J1>([&](auto J) { constexpr int j = decltype(J)::value; sincos_core_(qv[j], &tr[j].s, &tr[j].c); });
     }

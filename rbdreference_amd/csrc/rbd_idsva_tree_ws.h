@@ -102,8 +102,12 @@ __global__ __launch_bounds__(64 * TWS_W, RBD_TWS_MINBLOCKS) void rnea_grad_tree_
   // Buffer addressing: the block's base sits in a descriptor (four SGPRs), the lane's byte offset in ONE VGPR, the
   // slot's offset is a constant of the instruction stream.  (Plain pointers became 64-bit per-lane addresses, one
   // live register pair per eight slots: 600 spilled registers.)
-  const TwsBuf<T> PWB(pws + (size_t)blockIdx.x * (TWS_SLOTS * 64), lane);
-  const TwsBuf<T> EWB(ews + (size_t)blockIdx.x * (TWS_SLOTS * 64), lane);
+  // one region per BLOCK: in the single-wave layout the grid is (x, root) and the blocks (x, 0), (x, 1), ... of a
+  // multi-root robot run concurrently on the same lanes' slots (tree_pend_slot's in-chain region starts at 0 for every
+  // chain) -- they must not share a region (they did, indexed by blockIdx.x alone)
+  const size_t wblk = TWS_MULTI ? (size_t)blockIdx.x : (size_t)blockIdx.x * gridDim.y + blockIdx.y;
+  const TwsBuf<T> PWB(pws + wblk * (TWS_SLOTS * 64), lane);
+  const TwsBuf<T> EWB(ews + wblk * (TWS_SLOTS * 64), lane);
   auto PW = [&](int slot) { return TwsRef<T>{PWB, slot}; };
   auto EW = [&](int slot) { return TwsRef<T>{EWB, slot}; };
 

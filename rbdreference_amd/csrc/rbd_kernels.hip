@@ -1955,12 +1955,14 @@ constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
 // C-ABI (include/rbd_hip.h)
 // =============================================================================================
 #include "../../include/rbd_hip.h"
+#include "rbd_host.h"
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 constexpr int RBD_MAX_DEVICES = 16;
 
 
@@ -2066,35 +2068,77 @@ int resident_blocks(K kernel, int threads, size_t lds, int* out) {
 }
 }  // namespace
 
-// Library-owned scratch of the workspace gradient kernel (rbd_idsva_tree_ws.h): one buffer per (device, stream),
-// grown on demand and kept.  Launches on one stream are ordered and share it; launches on different streams get
-// different buffers.  The first call on a stream allocates (hipMalloc is not capturable: run a call once before
-// capturing it into a graph, as for every kernel that needs hipFuncSetAttribute).  One pool, owned by the COMMON unit.
+// Library-owned scratch of the workspace gradient kernel (rbd_idsva_tree_ws.h): one buffer per (device, stream), keyed
+// by the STREAM's device (hipStreamGetDevice; the null stream belongs to the calling thread's current device).
+// Launches on one stream are ordered and share it; launches on different streams get different buffers.
+// Lifetime rule: a buffer that was ever handed out is NEVER freed or moved by a later call -- launches in flight, bound
+// launches and captured hipGraphs may hold its address.  The callers ask for a size that depends on the kernel's
+// occupancy, not on B, so a (device, stream) normally sees one allocation; should a later call need more (another
+// kernel of the library), a larger buffer is allocated NEXT TO the old one, which is retired, not released.  Only
+// rbd_release_workspaces() frees (after hipDeviceSynchronize, by contract with no call of this library in flight and
+// no graph that contains one still alive).  The first call on a stream allocates (hipMalloc is not capturable: run a
+// call once before capturing it into a graph, as for every kernel that needs hipFuncSetAttribute); no call ever
+// synchronises the device.  One pool, owned by the COMMON unit.
 extern "C" __attribute__((visibility("hidden"))) int rbd_stream_workspace(void* stream, size_t bytes, void** out);
 #ifdef RBD_TU_COMMON
+namespace {
+struct RbdWsBuf { void* p = nullptr; size_t n = 0; };
+struct RbdWsEntry { RbdWsBuf cur; std::vector<RbdWsBuf> retired; };
+std::mutex& rbd_ws_mutex() { static std::mutex mu; return mu; }
+std::unordered_map<const void*, RbdWsEntry>* rbd_ws_pool() {
+  static std::unordered_map<const void*, RbdWsEntry> pool[RBD_MAX_DEVICES];
+  return pool;
+}
+int rbd_ws_device_of(void* stream, int* dev) {
+  int d = 0;
+  hipError_t e = stream ? hipStreamGetDevice((hipStream_t)stream, &d) : hipGetDevice(&d);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipGetDevice(&d); }
+  if (e != hipSuccess) return (int)e;
+  *dev = d;
+  return 0;
+}
+}  // namespace
 extern "C" int rbd_stream_workspace(void* stream, size_t bytes, void** out) {
-  struct Buf { void* p = nullptr; size_t n = 0; };
-  static std::mutex mu;
-  static std::unordered_map<const void*, Buf> pool[RBD_MAX_DEVICES];
   int dev = 0;
-  (void)hipGetDevice(&dev);
-  const int slot = dev >= 0 && dev < RBD_MAX_DEVICES ? dev : 0;
-  std::lock_guard<std::mutex> g(mu);
-  Buf& b = pool[slot][stream];
-  if (b.n < bytes) {
-    if (b.p) {   // hipFree waits for the device: the launches that used the old buffer are over
-      hipError_t e = hipFree(b.p);
-      b = Buf{};
-      if (e != hipSuccess) return hip_fail(e, "rbd workspace hipFree");
-    }
+  if (rbd_ws_device_of(stream, &dev) != 0) return hip_fail(hipErrorInvalidDevice, "rbd workspace: device of the stream");
+  if (dev < 0 || dev >= RBD_MAX_DEVICES) return fail(RBD_ERR_UNSUPPORTED, "rbd workspace: device index beyond RBD_MAX_DEVICES");
+  std::lock_guard<std::mutex> g(rbd_ws_mutex());
+  RbdWsEntry& en = rbd_ws_pool()[dev][stream];
+  if (en.cur.n < bytes) {
+    int cur_dev = dev;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != dev) (void)hipSetDevice(dev);            // allocate on the stream's device
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
+    if (cur_dev != dev) (void)hipSetDevice(cur_dev);
     if (e != hipSuccess) return hip_fail(e, "rbd workspace hipMalloc");
-    b.p = p;
-    b.n = bytes;
+    if (en.cur.p) en.retired.push_back(en.cur);               // may still be referenced: kept, not freed
+    en.cur.p = p;
+    en.cur.n = bytes;
   }
-  *out = b.p;
+  *out = en.cur.p;
   return 0;
+}
+extern "C" int rbd_release_workspaces(void) {
+  std::lock_guard<std::mutex> g(rbd_ws_mutex());
+  int cur_dev = 0;
+  const bool have_dev = hipGetDevice(&cur_dev) == hipSuccess;
+  if (!have_dev) (void)hipGetLastError();
+  int rc = 0;
+  for (int dev = 0; dev < RBD_MAX_DEVICES; ++dev) {
+    auto& m = rbd_ws_pool()[dev];
+    if (m.empty()) continue;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess && rc == 0) rc = hip_fail(e, "rbd_release_workspaces: hipDeviceSynchronize");
+    for (auto& kv : m) {
+      if (kv.second.cur.p) (void)hipFree(kv.second.cur.p);
+      for (auto& b : kv.second.retired) (void)hipFree(b.p);
+    }
+    m.clear();
+  }
+  if (have_dev) (void)hipSetDevice(cur_dev);
+  return rc;
 }
 #endif
 
@@ -2364,8 +2408,11 @@ int tree_ws_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_dam
     const int64_t need = (B + 63) / 64;
     if (xblocks > need) xblocks = need;
     const int64_t rows = xblocks * 64;
+    // sized by what is resident at once (never by B), one region per (x, root) block of the single-wave layout: a
+    // (device, stream) sees ONE allocation for this kernel, whatever batch sizes follow (rbd_stream_workspace)
+    const int64_t xres = resident / yroots > 0 ? resident / yroots : 1;
     void* ws = nullptr;
-    if ((rc = rbd_stream_workspace(stream, (size_t)rows * TWS_SLOTS * sizeof(T), &ws)) != 0) return rc;
+    if ((rc = rbd_stream_workspace(stream, (size_t)xres * 64 * yroots * TWS_SLOTS * sizeof(T), &ws)) != 0) return rc;
     T* pws = reinterpret_cast<T*>(ws);
     T* ews = pws + (size_t)64 * TWS_PATH_SLOTS;   // [block][slot][lane]: a block's entry slots follow its path slots
     for (int64_t r0 = 0; r0 < B; r0 += rows) {
@@ -2656,6 +2703,9 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   if (B == 0) return 0;
   if (!q || !qd || !u) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: q, qd, u must be non-null");
   if (want_grad ? !dqdd_du : !qdd) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: output pointer is null");
+  // refused HERE, before the first of the three launches (the gradient launcher's own check would come after two of them)
+  if (((reinterpret_cast<uintptr_t>(qdd) | reinterpret_cast<uintptr_t>(dqdd_du)) & 15u) != 0)
+    return fail(RBD_ERR_ARG, "rbd_forward_dynamics: output buffers must be 16-byte aligned");
   // qdd alone: the articulated-body sweep gives Minv (u - c) (:1372-1374) without forming Minv or c
   // (one launch, no workspace; 47 vs 76 us for the 7-DoF arm at B = 1M)
   if (!want_grad) return aba_launch<T>(q, qd, u, gravity, B, qdd, stream);
@@ -2864,166 +2914,166 @@ size_t rbd_fd_workspace_bytes(int64_t B, int elem_size) {
 #ifdef RBD_TU_RNEA_F32
 int rbd_rnea_f32(const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
                  float* c, float* v, float* a, float* f, void* stream) {
-  return rnea_launch<float>(q, qd, qdd, gravity, B, c, v, a, f, stream);
+  RbdStreamDevice sd_(stream); return rnea_launch<float>(q, qd, qdd, gravity, B, c, v, a, f, stream);
 }
 #endif
 #ifdef RBD_TU_RNEA_F32
 int rbd_rnea_fpass_f32(const float* q, const float* qd, const float* qdd, float gravity, int64_t B,
                        float* v, float* a, float* f, void* stream) {
-  return rnea_launch<float>(q, qd, qdd, gravity, B, nullptr, v, a, f, stream, 1);
+  RbdStreamDevice sd_(stream); return rnea_launch<float>(q, qd, qdd, gravity, B, nullptr, v, a, f, stream, 1);
 }
 int rbd_rnea_bpass_f32(const float* q, float* f, int64_t B, float* c, void* stream) {
-  return rnea_bpass_launch<float>(q, f, B, c, stream);
+  RbdStreamDevice sd_(stream); return rnea_bpass_launch<float>(q, f, B, c, stream);
 }
 #endif
 #ifdef RBD_TU_RNEA_F64
 int rbd_rnea_fpass_f64(const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
                        double* v, double* a, double* f, void* stream) {
-  return rnea_launch<double>(q, qd, qdd, gravity, B, nullptr, v, a, f, stream, 1);
+  RbdStreamDevice sd_(stream); return rnea_launch<double>(q, qd, qdd, gravity, B, nullptr, v, a, f, stream, 1);
 }
 int rbd_rnea_bpass_f64(const double* q, double* f, int64_t B, double* c, void* stream) {
-  return rnea_bpass_launch<double>(q, f, B, c, stream);
+  RbdStreamDevice sd_(stream); return rnea_bpass_launch<double>(q, f, B, c, stream);
 }
 #endif
 #ifdef RBD_TU_RNEA_F64
 int rbd_rnea_f64(const double* q, const double* qd, const double* qdd, double gravity, int64_t B,
                  double* c, double* v, double* a, double* f, void* stream) {
-  return rnea_launch<double>(q, qd, qdd, gravity, B, c, v, a, f, stream);
+  RbdStreamDevice sd_(stream); return rnea_launch<double>(q, qd, qdd, gravity, B, c, v, a, f, stream);
 }
 #endif
 #ifdef RBD_TU_GRADN_F32
 int rbd_grad_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* dc_du, void* stream) {
-  return rnea_grad_launch_q<float, false>(q, qd, nullptr, gravity, use_damping, B, c, dc_du, stream);
+  RbdStreamDevice sd_(stream); return rnea_grad_launch_q<float, false>(q, qd, nullptr, gravity, use_damping, B, c, dc_du, stream);
 }
 int rbd_grad_cols_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* v, float* a, float* f, float* dc_du, void* stream) {
-  return grad_cols_launch<float, false>(q, qd, nullptr, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+  RbdStreamDevice sd_(stream); return grad_cols_launch<float, false>(q, qd, nullptr, gravity, use_damping, B, c, v, a, f, dc_du, stream);
 }
 #endif
 #ifdef RBD_TU_GRADN_F64
 int rbd_grad_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* dc_du, void* stream) {
-  return rnea_grad_launch_q<double, false>(q, qd, nullptr, gravity, use_damping, B, c, dc_du, stream);
+  RbdStreamDevice sd_(stream); return rnea_grad_launch_q<double, false>(q, qd, nullptr, gravity, use_damping, B, c, dc_du, stream);
 }
 int rbd_grad_cols_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* v, double* a, double* f, double* dc_du, void* stream) {
-  return grad_cols_launch<double, false>(q, qd, nullptr, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+  RbdStreamDevice sd_(stream); return grad_cols_launch<double, false>(q, qd, nullptr, gravity, use_damping, B, c, v, a, f, dc_du, stream);
 }
 #endif
 #ifdef RBD_TU_GRAD_F32
 int rbd_rnea_grad_f32(const float* q, const float* qd, const float* qdd, float gravity,
                       int use_damping, int64_t B, float* c, float* dc_du, void* stream) {
-  return rnea_grad_launch<float>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+  RbdStreamDevice sd_(stream); return rnea_grad_launch<float>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
 }
 #endif
 #ifdef RBD_TU_GRAD_F64
 int rbd_rnea_grad_f64(const double* q, const double* qd, const double* qdd, double gravity,
                       int use_damping, int64_t B, double* c, double* dc_du, void* stream) {
-  return rnea_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
+  RbdStreamDevice sd_(stream); return rnea_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, dc_du, stream);
 }
 int rbd_rnea_with_grad_f64(const double* q, const double* qd, const double* qdd, double gravity, int use_damping, int64_t B,
                            double* c, double* v, double* a, double* f, double* dc_du, void* stream) {
-  return rnea_with_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+  RbdStreamDevice sd_(stream); return rnea_with_grad_launch<double>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
 }
 #endif
 #ifdef RBD_TU_GRAD_F32
 int rbd_rnea_with_grad_f32(const float* q, const float* qd, const float* qdd, float gravity, int use_damping, int64_t B,
                            float* c, float* v, float* a, float* f, float* dc_du, void* stream) {
-  return rnea_with_grad_launch<float>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
+  RbdStreamDevice sd_(stream); return rnea_with_grad_launch<float>(q, qd, qdd, gravity, use_damping, B, c, v, a, f, dc_du, stream);
 }
 #endif
 #ifdef RBD_TU_MINV_F32
-int rbd_crba_f32(const float* q, int64_t B, float* H, void* stream) { return crba_launch<float>(q, B, H, stream); }
+int rbd_crba_f32(const float* q, int64_t B, float* H, void* stream) { RbdStreamDevice sd_(stream); return crba_launch<float>(q, B, H, stream); }
 #endif
 #ifdef RBD_TU_MINV_F64
-int rbd_crba_f64(const double* q, int64_t B, double* H, void* stream) { return crba_launch<double>(q, B, H, stream); }
+int rbd_crba_f64(const double* q, int64_t B, double* H, void* stream) { RbdStreamDevice sd_(stream); return crba_launch<double>(q, B, H, stream); }
 #endif
 #ifdef RBD_TU_MINV_F32
 int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void* workspace,
                  size_t workspace_bytes, void* stream) {
-  return minv_launch<float>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+  RbdStreamDevice sd_(stream); return minv_launch<float>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
 }
 int rbd_minv_fd_f32(const float* q, int64_t B, float* Minv, void* workspace, size_t wsb, void* stream,
                     const float* u, const float* c, float* qdd) {
-  return minv_launch<float>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
+  RbdStreamDevice sd_(stream); return minv_launch<float>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
 }
 #endif
 #ifdef RBD_TU_FD_F32
 int rbd_aba_f32(const float* q, const float* qd, const float* tau, float gravity, int64_t B, float* qdd, void* stream) {
-  return aba_launch<float>(q, qd, tau, gravity, B, qdd, stream);
+  RbdStreamDevice sd_(stream); return aba_launch<float>(q, qd, tau, gravity, B, qdd, stream);
 }
 int rbd_forward_dynamics_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
                              float* qdd, void* workspace, size_t workspace_bytes, void* stream) {
-  return fd_launch<float>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
+  RbdStreamDevice sd_(stream); return fd_launch<float>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
 }
 int rbd_forward_dynamics_grad_f32(const float* q, const float* qd, const float* u, float gravity, int64_t B,
                                   float* qdd, float* dqdd_du, void* workspace, size_t workspace_bytes, void* stream) {
-  return fd_launch<float>(q, qd, u, gravity, B, qdd, dqdd_du, true, workspace, workspace_bytes, stream);
+  RbdStreamDevice sd_(stream); return fd_launch<float>(q, qd, u, gravity, B, qdd, dqdd_du, true, workspace, workspace_bytes, stream);
 }
 #endif
 #ifdef RBD_TU_FD_F64
 int rbd_aba_f64(const double* q, const double* qd, const double* tau, double gravity, int64_t B, double* qdd, void* stream) {
-  return aba_launch<double>(q, qd, tau, gravity, B, qdd, stream);
+  RbdStreamDevice sd_(stream); return aba_launch<double>(q, qd, tau, gravity, B, qdd, stream);
 }
 int rbd_forward_dynamics_f64(const double* q, const double* qd, const double* u, double gravity, int64_t B,
                              double* qdd, void* workspace, size_t workspace_bytes, void* stream) {
-  return fd_launch<double>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
+  RbdStreamDevice sd_(stream); return fd_launch<double>(q, qd, u, gravity, B, qdd, nullptr, false, workspace, workspace_bytes, stream);
 }
 int rbd_forward_dynamics_grad_f64(const double* q, const double* qd, const double* u, double gravity, int64_t B,
                                   double* qdd, double* dqdd_du, void* workspace, size_t workspace_bytes, void* stream) {
-  return fd_launch<double>(q, qd, u, gravity, B, qdd, dqdd_du, true, workspace, workspace_bytes, stream);
+  RbdStreamDevice sd_(stream); return fd_launch<double>(q, qd, u, gravity, B, qdd, dqdd_du, true, workspace, workspace_bytes, stream);
 }
 #endif
 #ifdef RBD_TU_MINV_F64
 int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, void* workspace,
                  size_t workspace_bytes, void* stream) {
-  return minv_launch<double>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
+  RbdStreamDevice sd_(stream); return minv_launch<double>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
 }
 int rbd_minv_fd_f64(const double* q, int64_t B, double* Minv, void* workspace, size_t wsb, void* stream,
                     const double* u, const double* c, double* qdd) {
-  return minv_launch<double>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
+  RbdStreamDevice sd_(stream); return minv_launch<double>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
 }
 #endif
 
 #ifdef RBD_TU_PASS_F32
 int rbd_rnea_grad_fpass_dq_f32(const float* q, const float* qd, const float* v, const float* a, float gravity, int64_t B,
                                float* dv_dq, float* da_dq, float* df_dq, void* stream) {
-  return grad_fpass_launch<float, true>(q, qd, v, a, gravity, B, dv_dq, da_dq, df_dq, stream);
+  RbdStreamDevice sd_(stream); return grad_fpass_launch<float, true>(q, qd, v, a, gravity, B, dv_dq, da_dq, df_dq, stream);
 }
 int rbd_rnea_grad_fpass_dqd_f32(const float* q, const float* qd, const float* v, int64_t B, float* dv_dqd, float* da_dqd,
                                 float* df_dqd, void* stream) {
-  return grad_fpass_launch<float, false>(q, qd, v, nullptr, float(0), B, dv_dqd, da_dqd, df_dqd, stream);
+  RbdStreamDevice sd_(stream); return grad_fpass_launch<float, false>(q, qd, v, nullptr, float(0), B, dv_dqd, da_dqd, df_dqd, stream);
 }
 int rbd_rnea_grad_bpass_dq_f32(const float* q, const float* f, float* df_dq, int64_t B, float* dc_dq, void* stream) {
-  return grad_bpass_launch<float, true>(q, f, df_dq, 0, B, dc_dq, stream);
+  RbdStreamDevice sd_(stream); return grad_bpass_launch<float, true>(q, f, df_dq, 0, B, dc_dq, stream);
 }
 int rbd_rnea_grad_bpass_dqd_f32(const float* q, float* df_dqd, int use_damping, int64_t B, float* dc_dqd, void* stream) {
-  return grad_bpass_launch<float, false>(q, nullptr, df_dqd, use_damping, B, dc_dqd, stream);
+  RbdStreamDevice sd_(stream); return grad_bpass_launch<float, false>(q, nullptr, df_dqd, use_damping, B, dc_dqd, stream);
 }
 int rbd_minv_bpass_f32(const float* q, int64_t B, float* Minv, float* F, float* U, float* Dinv, void* stream) {
-  return minv_bpass_launch<float>(q, B, Minv, F, U, Dinv, stream);
+  RbdStreamDevice sd_(stream); return minv_bpass_launch<float>(q, B, Minv, F, U, Dinv, stream);
 }
 int rbd_minv_fpass_f32(const float* q, int64_t B, float* Minv, float* F, const float* U, const float* Dinv, void* stream) {
-  return minv_fpass_launch<float>(q, B, Minv, F, U, Dinv, stream);
+  RbdStreamDevice sd_(stream); return minv_fpass_launch<float>(q, B, Minv, F, U, Dinv, stream);
 }
 #endif
 #ifdef RBD_TU_PASS_F64
 int rbd_rnea_grad_fpass_dq_f64(const double* q, const double* qd, const double* v, const double* a, double gravity, int64_t B,
                                double* dv_dq, double* da_dq, double* df_dq, void* stream) {
-  return grad_fpass_launch<double, true>(q, qd, v, a, gravity, B, dv_dq, da_dq, df_dq, stream);
+  RbdStreamDevice sd_(stream); return grad_fpass_launch<double, true>(q, qd, v, a, gravity, B, dv_dq, da_dq, df_dq, stream);
 }
 int rbd_rnea_grad_fpass_dqd_f64(const double* q, const double* qd, const double* v, int64_t B, double* dv_dqd, double* da_dqd,
                                 double* df_dqd, void* stream) {
-  return grad_fpass_launch<double, false>(q, qd, v, nullptr, double(0), B, dv_dqd, da_dqd, df_dqd, stream);
+  RbdStreamDevice sd_(stream); return grad_fpass_launch<double, false>(q, qd, v, nullptr, double(0), B, dv_dqd, da_dqd, df_dqd, stream);
 }
 int rbd_rnea_grad_bpass_dq_f64(const double* q, const double* f, double* df_dq, int64_t B, double* dc_dq, void* stream) {
-  return grad_bpass_launch<double, true>(q, f, df_dq, 0, B, dc_dq, stream);
+  RbdStreamDevice sd_(stream); return grad_bpass_launch<double, true>(q, f, df_dq, 0, B, dc_dq, stream);
 }
 int rbd_rnea_grad_bpass_dqd_f64(const double* q, double* df_dqd, int use_damping, int64_t B, double* dc_dqd, void* stream) {
-  return grad_bpass_launch<double, false>(q, nullptr, df_dqd, use_damping, B, dc_dqd, stream);
+  RbdStreamDevice sd_(stream); return grad_bpass_launch<double, false>(q, nullptr, df_dqd, use_damping, B, dc_dqd, stream);
 }
 int rbd_minv_bpass_f64(const double* q, int64_t B, double* Minv, double* F, double* U, double* Dinv, void* stream) {
-  return minv_bpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
+  RbdStreamDevice sd_(stream); return minv_bpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
 }
 int rbd_minv_fpass_f64(const double* q, int64_t B, double* Minv, double* F, const double* U, const double* Dinv, void* stream) {
-  return minv_fpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
+  RbdStreamDevice sd_(stream); return minv_fpass_launch<double>(q, B, Minv, F, U, Dinv, stream);
 }
 #endif
 

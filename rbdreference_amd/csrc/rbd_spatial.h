@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <type_traits>
+#include "rbd_sincos.h"
 
 namespace rbdk {
 using namespace rbdm;
@@ -262,81 +263,13 @@ RBD_DEV T dot6(const T (&x)[6], const T (&y)[6]) {
   return fma_(x[5], y[5], fma_(x[4], y[4], fma_(x[3], y[3], fma_(x[2], y[2], fma_(x[1], y[1], x[0] * y[0])))));
 }
 
-// fp32 sin / cos of a joint angle.  |q| <= 8192: two-constant Cody-Waite reduction by pi/2 (exact under FMA) and the
-// classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]: max abs error 9.2e-8 over the range (numpy
-// emulation, 6 M samples; a correctly rounded result has 3e-8), ~22 instructions against ~45 for sincosf, which
-// carries the Payne-Hanek path for huge arguments.  Larger |q| take sincosf (a branch no lane takes in practice).
-// The quadrant fix-up is bit arithmetic (v_bfe_i32 / v_bfi_b32 / shift / and / xor), not compares and selects: measured
-// (tools/ubench/pk_issue.hip) a v_cndmask_b32 costs a wave 6.4 cycles in its VOP3 form and 16.7 in the VOP2 form that
-// reads VCC, a v_cmp 9, against 5.2-5.7 for a plain VOP2 instruction -- and the selects of two waves do not overlap.
-RBD_DEV void sincos_core_(float q, float* s, float* c) {                      // |q| <= 8192
-  const float kf = __builtin_rintf(q * 0.63661977236758134f);                 // q * 2 / pi
-  float r = __builtin_fmaf(-kf, 1.5707963705062866f, q);                      // pi/2 = hi + mid (+ 1.8e-15)
-  r = __builtin_fmaf(-kf, -4.371138828673793e-08f, r);
-  const int k = (int)kf;
-  const float z = r * r;
-  float sp = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
-  sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
-  sp = __builtin_fmaf(sp * z, r, r);
-  float cp = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
-  cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
-  cp = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
-  const unsigned us = __builtin_bit_cast(unsigned, sp), uc = __builtin_bit_cast(unsigned, cp);
-  const unsigned m = (unsigned)-(k & 1);                                      // all ones when k is odd: sin and cos trade places
-  unsigned ss = (uc & m) | (us & ~m);
-  unsigned cc = (us & m) | (uc & ~m);
-  ss ^= ((unsigned)k << 30) & 0x80000000u;                                    // sin changes sign in quadrants 2, 3
-  cc ^= ((unsigned)(k + 1) << 30) & 0x80000000u;                              // cos in quadrants 1, 2
-  *s = __builtin_bit_cast(float, ss);
-  *c = __builtin_bit_cast(float, cc);
-}
-RBD_DEV void sincos_(float q, float* s, float* c) {
-  // WAVE-UNIFORM branch (ballot over the active lanes), not a lane-masked one: see the fp64 routine below for what a
-  // lane-masked branch around a library routine cost.  Any lane beyond the range (or non-finite) sends its wave to sincosf.
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(q) <= 8192.0f)) != 0, 0)) { sincosf(q, s, c); return; }
-  sincos_core_(q, s, c);
-}
-// fp64: own three-constant Cody-Waite reduction (pi/2 = 33 + 33 + 53 bits: k * P1 and k * P2 are exact for |k| < 2^20) and
-// the degree-13 / degree-14 minimax polynomials of the classic libm kernels on [-pi/4, pi/4]; max abs error 2.1e-16 for
-// |q| <= 1e6 (4 M samples per range against long double, tools/ubench/sincos_f64_check.c), quadrant fix-up in bit
-// arithmetic like the fp32 routine.  No lane-divergent control flow: the library routine (Payne-Hanek for huge
-// arguments) is behind a WAVE-UNIFORM branch, taken when any active lane has |q| > 1e6 or a non-finite q.
-// Why it matters beyond speed: the library's lane-masked if / else leaves EXEC = 0 on entry to a side no lane takes,
-// and in register-starved fp64 kernels (AGPRs in use) the compiler placed a live-range copy (v_accvgpr_write of a
-// zero that later becomes the high half of a 64-bit address offset) in exactly that window, where it does nothing:
-// rnea_grad_idsva_kernel<double> of a dense 7-chain read through a garbage pointer (found with rocgdb, round 3).
-RBD_DEV void sincos_core_(double q, double* s, double* c) {                     // |q| <= 1e6
-  const double kf = __builtin_rint(q * 6.36619772367581382433e-01);           // q * 2 / pi
-  double r = __builtin_fma(-kf, 1.57079632673412561417e+00, q);
-  r = __builtin_fma(-kf, 6.07710050630396597660e-11, r);
-  r = __builtin_fma(-kf, 2.02226624879595063154e-21, r);
-  const int k = (int)kf;
-  const double z = r * r;
-  double sp = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  sp = __builtin_fma(sp, z, 2.75573137070700676789e-06);
-  sp = __builtin_fma(sp, z, -1.98412698298579493134e-04);
-  sp = __builtin_fma(sp, z, 8.33333333332248946124e-03);
-  sp = __builtin_fma(sp, z, -1.66666666666666324348e-01);
-  sp = __builtin_fma(sp * z, r, r);
-  double cp = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  cp = __builtin_fma(cp, z, -2.75573143513906633035e-07);
-  cp = __builtin_fma(cp, z, 2.48015872894767294178e-05);
-  cp = __builtin_fma(cp, z, -1.38888888888741095749e-03);
-  cp = __builtin_fma(cp, z, 4.16666666666666019037e-02);
-  cp = __builtin_fma(cp * z, z, __builtin_fma(-0.5, z, 1.0));
-  const unsigned long long us = __builtin_bit_cast(unsigned long long, sp), uc = __builtin_bit_cast(unsigned long long, cp);
-  const unsigned long long m = (unsigned long long)-(long long)(k & 1);      // all ones when k is odd: sin and cos trade places
-  unsigned long long ss = (uc & m) | (us & ~m);
-  unsigned long long cc = (us & m) | (uc & ~m);
-  ss ^= ((unsigned long long)(unsigned)k << 62) & 0x8000000000000000ull;      // sin changes sign in quadrants 2, 3
-  cc ^= ((unsigned long long)(unsigned)(k + 1) << 62) & 0x8000000000000000ull;   // cos in quadrants 1, 2
-  *s = __builtin_bit_cast(double, ss);
-  *c = __builtin_bit_cast(double, cc);
-}
-RBD_DEV void sincos_(double q, double* s, double* c) {
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabs(q) <= 1.0e6)) != 0, 0)) { sincos(q, s, c); return; }
-  sincos_core_(q, s, c);
-}
+// sin / cos of a joint angle: rbd_sincos.h -- own fast paths (Cody-Waite + minimax polynomials, bit-arithmetic quadrant
+// fix-up) and an own BRANCH-FREE wide path (Payne-Hanek for huge angles, NaN for non-finite ones) behind a wave-uniform
+// branch.  No libm / ocml routine is called anywhere in the device code: their lane-masked if / else bodies are where
+// the round-3 aperture fault came from (the header tells the story; tools/isa_exec_audit.py checks the ISA).
+using rbdsc::sincos_;
+using rbdsc::sincos_core_;
+using rbdsc::sincos_wide_;
 
 template <int J, class T>
 RBD_DEV JTrig<T> make_trig(T q) {

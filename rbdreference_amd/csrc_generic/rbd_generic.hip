@@ -20,6 +20,7 @@
 #include <new>
 
 #include "../../include/rbd_generic.h"
+#include "../csrc/rbd_sincos.h"
 
 #define GDEV __device__ __forceinline__
 
@@ -44,8 +45,10 @@ struct DevModel {
   T mass[MB], com[MB][3], Ic[MB][6], sa[MB][3];
 };
 
-GDEV void sincos_g(float x, float* s, float* c) { sincosf(x, s, c); }
-GDEV void sincos_g(double x, double* s, double* c) { sincos(x, s, c); }
+// own sin / cos (csrc/rbd_sincos.h): fast path + branch-free wide path behind a wave-uniform branch, no libm / ocml
+// routine (their lane-masked if / else bodies are the round-3 fault's cause, see that header)
+GDEV void sincos_g(float x, float* s, float* c) { rbdsc::sincos_(x, s, c); }
+GDEV void sincos_g(double x, double* s, double* c) { rbdsc::sincos_(x, s, c); }
 
 // (f1, f2) of X(q) = X0 + Xs f1 + Xc f2
 template <class T>

@@ -53,7 +53,9 @@ def _snap(M: np.ndarray, tol: float = 1e-14) -> np.ndarray:
 
 def _rot_axis(k: int, q: float) -> np.ndarray:
     """Coordinate-transform rotation about axis k (transpose of the active rotation)."""
-    c, s = math.cos(q), math.sin(q)
+    # (math.cos raises for an infinite angle; numpy's answer for it -- NaN -- is what an `Xmat(q)` closure built on numpy
+    # hands the reference, and what the kernels produce; finite angles are untouched)
+    c, s = (math.cos(q), math.sin(q)) if math.isfinite(q) else (float("nan"), float("nan"))
     if k == 0:
         return np.array([[1.0, 0, 0], [0, c, s], [0, -s, c]])
     if k == 1:

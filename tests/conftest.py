@@ -60,6 +60,8 @@ def make_robot(name):
         return random_tree([-1, 0, 1, 2, 3, 4, 1, 6, 7, 8, 1, 10, 11, 12], seed=41, name=name)
     if name == "random_forest_n8":      # interleaved root subtrees + a branch (no per-root groups)
         return random_tree([-1, -1, 0, 1, 2, 0, 3, 5], seed=33, name=name)
+    if name == "random_twochains_n18":  # two independent nine-body chains (fp64 workspace tree kernel, one block per root)
+        return random_tree([-1, 0, 1, 2, 3, 4, 5, 6, 7, -1, 9, 10, 11, 12, 13, 14, 15, 16], seed=57, name=name)
     raise KeyError(name)
 
 

@@ -665,14 +665,16 @@ def test_tree_gradient_kernel_forced_on_every_robot():
 
 
 @pytest.mark.parametrize("name,forced", [("atlas_like", False), ("random_limbs_n14", False), ("iiwa_like", True),
-                                         ("random_chain_n7", True)])
+                                         ("random_chain_n7", True), ("random_twochains_n18", False)])
 def test_fp64_workspace_tree_kernel(name, forced):
     """fp64 rnea_grad of trees too big for registers + LDS (rbd_idsva_tree_ws.h): path vectors, pending entries and
     parked composites in a library-owned global workspace.  Default for the robots whose fp32 default is the tree
     kernel (Atlas, the 14-body limbs robot), on request for the chains.  Checked: the golden vectors of the real
     reference (qdd given / None, damping), a ragged batch row by row, a batch that walks the workspace in several
     chunks (rows on both sides of every chunk boundary are bit-identical to a small call and agree with the oracle),
-    and two streams at once (one workspace per stream)."""
+    and two streams at once (one workspace per stream).  Multi-root robots on the single-wave layout (one block per
+    root: the two nine-body chains, whose default kernel this is) are the ADVICE r3 case: the blocks of different
+    roots run concurrently and each needs its own workspace region."""
     from oracle import rbd_oracle as orc
     torch = _torch()
     from rbdreference_amd._lib import RBD_GRAD_KERNEL_AUTO, RBD_GRAD_KERNEL_TREE, RBD_OP_RNEA_GRAD, RBD_OPT_GRAD_KERNEL

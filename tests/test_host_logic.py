@@ -183,6 +183,50 @@ def test_kernels_of_built_libraries_do_not_spill():
     assert not bad, bad
 
 
+def test_no_vector_write_sits_in_an_exec_masked_window_and_no_kernel_calls_out():
+    """The round-3 aperture fault (DESIGN.md section 3.1 a' (xv)) was a register copy the compiler had placed at the head of
+    the ELSE block of the device library's lane-masked `if (|x| large)`, before EXEC is restored there.  Round 4 removed
+    the library sin / cos (csrc/rbd_sincos.h is straight-line code); this guards the ISA of whatever libraries are built:
+    no vector instruction between a label `s_cbranch_execz` jumps to and the first rewrite of EXEC, no out-of-line
+    call, and no lane-masked if / ELSE at all in the fp64 kernels that keep state in AGPRs (tools/isa_exec_audit.py;
+    reads the code objects, no GPU)."""
+    import glob
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_exec_audit
+    libs = sorted(glob.glob(os.path.join(ROOT, "rbdreference_amd", "_build", "librbd_*_*.so")))
+    libs = [l for l in libs if l.count(".") == 1 and any(k in l for k in ("iiwa_like", "random_chain_n7", "atlas_like", "random_twochains_n18", "fb_quadruped_like"))]
+    if not libs:
+        pytest.skip("no per-robot library built yet")
+    for lib in libs:
+        for dem, n, else_blocks, execz_targets, calls, masked in isa_exec_audit.audit(lib):
+            assert not masked, (os.path.basename(lib), dem, masked[:4])
+            assert calls == 0, (os.path.basename(lib), dem, "out-of-line call")
+            if "double" in dem and ("rnea_grad_idsva_kernel" in dem or "rnea_grad_kernel<" in dem):
+                assert else_blocks == 0, (os.path.basename(lib), dem, else_blocks)
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="hipcc not available")
+def test_capi_host_code_is_clean_under_asan_and_ubsan():
+    """SURVEY.md section 5 / VERDICT r3 item 9: the host side of the C-ABI (argument, alignment and workspace checks,
+    option atomics, kernel-name queries, the workspace pool) compiled with -fsanitize=address,undefined (host only) and
+    driven without a GPU by tools/asan_host_checks.py in a child process that preloads the sanitizer runtime.  A report
+    aborts the child.  Small robots: a 4-body tree (one-lane kernels) -- the launch logic is the same templates for every
+    robot."""
+    import subprocess
+    import sys
+    from rbdreference_amd.build import build_sanitized, sanitizer_runtime
+    from rbdreference_amd.robot import random_tree
+    m = pack_robot(random_tree([-1, 0, 0, 2], seed=3, name="asan_probe_n4"))
+    lib = build_sanitized(m)
+    assert lib.endswith(".asan.so") and os.path.exists(lib)
+    env = dict(os.environ, LD_PRELOAD=sanitizer_runtime(), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_host_checks.py"), lib], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan host checks OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_robot_name_cannot_inject_code_into_the_generated_header():
     """the name comes from the caller or from a URDF's <robot name=...>; the generated header is
     compiled and dlopen'ed in-process, so only [A-Za-z0-9_] (at most 63 characters) may reach it or the file name."""

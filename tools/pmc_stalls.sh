@@ -13,12 +13,15 @@ python3 - <<P
 import csv, glob, os
 from collections import defaultdict
 acc = defaultdict(list)
+names = set()
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "idsva" in r.get("Kernel_Name", ""):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            names.add(r["Kernel_Name"].split("(")[0].replace("void rbdk::", ""))
 with open("$OUT/pmc_stalls.txt", "w") as fh:
-    fh.write("# rnea_grad_idsva_kernel<float,true,false>, B = 1 048 576: mean counter value per dispatch (SQ_* cycle counters in quad-cycles)\n")
+    # the header names the kernel(s) the rows actually belong to (it used to be a literal string)
+    fh.write("# " + " | ".join(sorted(names)) + ", B = 1 048 576: mean counter value per dispatch (SQ_* cycle counters in quad-cycles)\n")
     for k, v in sorted(acc.items()):
         line = f"{k:34s} {sum(v)/len(v):16.0f}  n={len(v)}"
         print(line); fh.write(line + "\n")
