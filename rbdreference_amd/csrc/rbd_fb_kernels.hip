@@ -316,9 +316,10 @@ int fdg_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* 
   if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
   hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
   if ((rc = grad_fb_launch<T>("rbd_forward_dynamics_grad", q, qd, (const T*)qdd, gravity, 0, B, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr, dc, stream)) != 0) return rc;   // :1378
-  const int64_t mb = (B + FBMM_C - 1) / FBMM_C;
+  constexpr int MMC = negmm_cfgs<T, NV>();
+  const int64_t mb = (B + MMC - 1) / MMC;
   if (mb > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
-  hipLaunchKernelGGL((fb_neg_mm_kernel<T>), dim3((unsigned)mb), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);   // :1382-1383
+  hipLaunchKernelGGL((neg_mm_kernel<T, NV>), dim3((unsigned)mb), dim3(negmm_threads<T, NV>()), 0, (hipStream_t)stream, (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);   // :1382-1383
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_forward_dynamics_grad (floating base) launch");
 }

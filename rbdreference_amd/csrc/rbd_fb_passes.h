@@ -9,6 +9,7 @@
 // by pass with the reference: they move its O(n^2) six-vectors through HBM by definition and store element by
 // element; one lane per (configuration, derivative / matrix column), bodies unrolled, columns a run-time loop.
 #pragma once
+#include "rbd_negmm.h"
 #include "rbd_fb.h"
 
 namespace rbdk {
@@ -335,33 +336,5 @@ __global__ __launch_bounds__(64, 1) void fb_minv_fpass_kernel(const T* __restric
   }
 }
 
-// ---- out [B, NV, 2 NV] = -Minv dc_du   (:1381-1384) ------------------------------------------------------------------------
-// One thread per (configuration, column of dc_du): it reads its column (the threads of a configuration read whole
-// rows: coalesced), keeps the nv results in registers, and takes Minv from an LDS copy the block staged with flat
-// loads (the threads of a configuration read the same entry: a broadcast).  FBMM_C configurations per 256-thread block.
-constexpr int FBMM_C = 256 / (2 * NV) > 0 ? 256 / (2 * NV) : 1;
-template <class T>
-__global__ __launch_bounds__(256) void fb_neg_mm_kernel(const T* __restrict__ Minv, const T* __restrict__ dc, long long B,
-                                                        T* __restrict__ out) {
-  __shared__ T Ms[FBMM_C * NV * NV];
-  const long long cfg0 = (long long)blockIdx.x * FBMM_C;
-  const long long rem = B - cfg0;
-  const int nvalid = rem < FBMM_C ? (int)rem : FBMM_C;
-  for (int g = threadIdx.x; g < nvalid * NV * NV; g += 256) Ms[g] = Minv[cfg0 * (NV * NV) + g];
-  __syncthreads();
-  const int cl = threadIdx.x / (2 * NV), c = threadIdx.x - cl * (2 * NV);
-  if (cl >= nvalid) return;
-  const T* D = dc + (cfg0 + cl) * (NV * 2 * NV) + c;
-  const T* M = Ms + cl * (NV * NV);
-  T acc[NV];
-  sfor<0, NV>([&](auto R) { acc[decltype(R)::value] = T(0); });
-#pragma unroll 2
-  for (int k = 0; k < NV; ++k) {
-    const T d = D[k * 2 * NV];
-    sfor<0, NV>([&](auto R) { constexpr int r = decltype(R)::value; acc[r] = fma_(-M[r * NV + k], d, acc[r]); });
-  }
-  T* O = out + (cfg0 + cl) * (NV * 2 * NV) + c;
-  sfor<0, NV>([&](auto R) { constexpr int r = decltype(R)::value; O[r * 2 * NV] = acc[r]; });
-}
-
+// ---- out [B, NV, 2 NV] = -Minv dc_du   (:1381-1384): neg_mm_kernel<T, NV> of rbd_negmm.h (flat 16-byte copies through LDS) ----
 }  // namespace rbdk

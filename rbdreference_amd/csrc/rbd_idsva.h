@@ -141,18 +141,24 @@ static __device__ unsigned long long ids_stamp_buf[IDS_STAMP_BLOCKS * IDS_STAMP_
 // SIMD a waiting wave halves the SIMD's issue rate: a lone wave issues one VALU instruction per 4
 // cycles).  Same signature and output layout as rnea_grad_kernel<T, HAS_QDD, false>.
 // ---------------------------------------------------------------------------------------------
-// FDG (single-group robots only) = forward_dynamics_grad epilogue (RBDReference.py:1376-1384): when
-// the sweep is over and every lane holds its finished dc_du rows in registers, the block's Minv rows
-// ([64][n*n], contiguous in `minv_in`) are staged through the idle tile with coalesced loads and
-// [qdd_dq | qdd_dqd] = -Minv dc_du replaces the rows before they leave.  No extra LDS, no dc_du round
-// trip through HBM.
+// FDG (one-chain robots only) = forward_dynamics_grad epilogue (RBDReference.py:1376-1384): when the sweep is over and
+// every lane holds its finished dc_du rows in registers, the lane reads ITS Minv -- the upper triangle, from the lane-major
+// workspace [tile][n (n + 1) / 2][64 lanes] that fd_pre_kernel (rbd_fd_chain.h) filled: one coalesced load per entry -- and
+// [qdd_dq | qdd_dqd] = -Minv dc_du replaces the rows column by column, in place, before they leave.  No LDS, no dense
+// Minv, no dc_du round trip through HBM.  (Round 3 staged the dense [64][n n] Minv rows through the idle tile and built
+// the product in a second set of 2 n^2 registers: fp32 only -- in fp64 that copy alone is 196 VGPRs.)
+constexpr int FDC_NP = N * (N + 1) / 2;                       // packed upper triangle of Minv, row-major: (i, j), i <= j
+constexpr int fdc_slot(int i, int j) { return i * N - i * (i - 1) / 2 + (j - i); }
+constexpr int fdc_sym(int i, int j) { return i <= j ? fdc_slot(i, j) : fdc_slot(j, i); }
+// workspace scalars for a batch of B rows: whole tiles (the lanes past the batch hold copies of its last row, which the
+// ragged tile of the gradient kernels relies on)
+constexpr size_t fdc_ws_scalars(long long B) { return (size_t)((B + 63) / 64) * FDC_NP * 64; }
 template <class T, bool HAS_QDD, bool FDG = false>
 __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                                 const T* __restrict__ qdd, T grav, int use_damping,
                                                                 long long B, T* __restrict__ c_out,
                                                                 T* __restrict__ dcdu, const T* __restrict__ minv_in = nullptr) {
-  static_assert(!FDG || grad_max_rows() == N, "fused -Minv epilogue: single-group robots only");
-  static_assert(!FDG || 64 * IDS_TS >= 64 * N * N, "the tile must hold the block's Minv rows");
+  static_assert(!FDG || (grad_max_rows() == N && n_groups() == 1), "fused -Minv epilogue: one-chain robots only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
@@ -598,40 +604,27 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void rnea_grad_idsva_ke
     IDS_WAVE_SYNC();                                       // every lane has left the tile
 
     if constexpr (FDG) {
-      // the block's Minv rows through the idle tile ([64][n*n], coalesced loads all issued together),
-      // then O = -Minv E row by row (a row of Minv is re-read from LDS for its 2n products)
+      T mk[FDC_NP];
       {
-        T ms[N * N];
-        const T* msrc = minv_in + cfg0 * (N * N);
-        const int lim = nvalid * N * N;
-        int g0 = lane;
-        asm volatile("" : "+v"(g0));
-        sfor<0, N * N>([&](auto K_) {
-          constexpr int k = decltype(K_)::value;
-          const int g = g0 + CFGS * k;
-          ms[k] = msrc[g < lim ? g : 0];
-        });
-        sfor<0, N * N>([&](auto K_) { constexpr int k = decltype(K_)::value; tile[g0 + CFGS * k] = ms[k]; });
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const T* mp = minv_in + (size_t)t * (FDC_NP * 64) + lo;
+        sfor<0, FDC_NP>([&](auto S_) { constexpr int s_ = decltype(S_)::value; mk[s_] = mp[s_ * 64]; });
       }
-      IDS_WAVE_SYNC();
-      // (lanes beyond nvalid repeat row nvalid - 1 exactly: the ragged flush relies on it)
-      const T* mrow = tile + (lane < nvalid ? lane : nvalid - 1) * (N * N);
-      T O[RW];
-      sfor<0, N>([&](auto I_) {
-        constexpr int i = decltype(I_)::value;
-        T mi[N];
-        sfor<0, N>([&](auto K_) { constexpr int k = decltype(K_)::value; mi[k] = mrow[i * N + k]; });
-        sfor<0, GRAD_ROW>([&](auto C_) {
-          constexpr int c = decltype(C_)::value;
-          T o = T(0);
-          sfor<0, N>([&](auto K_) { constexpr int k = decltype(K_)::value; o = fma_(-mi[k], E[k * GRAD_ROW + c], o); });
-          O[i * GRAD_ROW + c] = o;
+      // E <- -Minv E (:1381-1383), column by column in place; Minv is symmetric (:799-804)
+      sfor<0, GRAD_ROW>([&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        T x[N];
+        sfor<0, N>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = E[k * GRAD_ROW + c]; });
+        sfor<0, N>([&](auto I_) {
+          constexpr int i = decltype(I_)::value;
+          T o = -(mk[fdc_sym(i, 0)] * x[0]);
+          sfor<1, N>([&](auto K_) { constexpr int k = decltype(K_)::value; o = fma_(-mk[fdc_sym(i, k)], x[k], o); });
+          E[i * GRAD_ROW + c] = o;
         });
       });
-      sfor<0, RW>([&](auto K_) { constexpr int k = decltype(K_)::value; E[k] = O[k]; });
-      IDS_WAVE_SYNC();                                     // every lane has read its Minv rows
-      // this variant's epilogue needs every register: the next inputs are requested behind it and waited
-      // for at the top of the next tile (together with this tile's stores)
+      // this variant requests the next inputs behind its epilogue; they are waited for at the top of the next tile
+      // (together with this tile's stores)
       prefetch();
     }
 

@@ -30,6 +30,9 @@ constexpr bool ids_pipe_ok_() {
 constexpr bool IDS_PIPE_OK = ids_pipe_ok_();
 
 #define IDS_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef IDS_FDG_LOAD_AT
+#define IDS_FDG_LOAD_AT 0                           // FDG: body (from the root) at the start of whose backward step the tile's Minv is requested
+#endif
 // Parking of cold per-body values in the tile (rbd_idsva.h) is OFF here: with the flush out of the way this
 // kernel's register peak is lower (236 VGPRs with every park, 248 with none, no scratch either way), and every
 // park is two LDS writes, two reads and a wait in a wave that has only one partner to hide it -- interleaved A/B
@@ -55,11 +58,11 @@ constexpr int ids_pipe_rows_a(int rows) {           // bodies whose entries wait
 template <class X>
 RBD_DEV void ids_undef(X& x) { asm volatile("" : "=v"(x)); }
 
-template <class T, bool HAS_QDD>
+template <class T, bool HAS_QDD, bool FDG = false>
 __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __restrict__ q, const T* __restrict__ qd,
                                                                     const T* __restrict__ qdd, T grav, int use_damping,
                                                                     long long B, T* __restrict__ c_out,
-                                                                    T* __restrict__ dcdu) {
+                                                                    T* __restrict__ dcdu, const T* __restrict__ minv_pk) {
   static_assert(sizeof(T) == 4, "fp32 kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
@@ -95,6 +98,8 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
   T cv[N];
   T Rm[3][3], pw[3], v[6], a[6];                           // state of the current body: R (body -> world), origin, v, a
   T E[RW];                                                 // finished rows, final layout [r * 2n + c]
+  T mk[FDG ? FDC_NP : 1];                                  // forward_dynamics_grad: this lane's Minv (upper triangle) of the current tile
+  long long tcur = 0;                                      // ... whose index the backward sweep needs for that request
 
   auto load_inputs = [&](long long tt, bool dummy) {
     const long long c0 = tt * CFGS;
@@ -245,6 +250,17 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
 #ifndef RBD_EXP_NO_PIN_READBACK
         IDS_SB();
 #endif
+      }
+      if constexpr (FDG && j == row0 + (rows > IDS_FDG_LOAD_AT ? IDS_FDG_LOAD_AT : rows - 1)) {
+        // forward_dynamics_grad: this lane's Minv (upper triangle) comes back from the workspace fd_pre_kernel filled --
+        // one coalesced dword load per entry, requested late in the sweep (registers are free by now) so that the rest
+        // of the sweep and the read-back of the parked entries cover the latency
+        IDS_SB();
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        const T* mp = minv_pk + (size_t)tcur * (FDC_NP * 64) + lo;
+        sfor<0, FDC_NP>([&](auto S_) { constexpr int s_ = decltype(S_)::value; mk[s_] = mp[s_ * 64]; });
+        IDS_SB();
       }
       // world rigid inertia of body j about the world origin
       RInertia<T> L;
@@ -611,9 +627,24 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
     park(std::integral_constant<int, 1>{});
     sfor<2, N>([&](auto J) { fwd_body(J); park(J); });
 
+    tcur = t;
     backward(has_next ? tnext : t, !has_next);
 
     readback();
+    if constexpr (FDG) {
+      // E <- -Minv E (:1381-1383), column by column in place: 2 n columns x n^2 FMAs; Minv is symmetric (:799-804)
+      sfor<0, GRAD_ROW>([&](auto C_) {
+        constexpr int c = decltype(C_)::value;
+        T x[N];
+        sfor<0, N>([&](auto K_) { constexpr int k = decltype(K_)::value; x[k] = E[k * GRAD_ROW + c]; });
+        sfor<0, N>([&](auto I_) {
+          constexpr int i = decltype(I_)::value;
+          T o = -(mk[fdc_sym(i, 0)] * x[0]);
+          sfor<1, N>([&](auto K_) { constexpr int k = decltype(K_)::value; o = fma_(-mk[fdc_sym(i, k)], x[k], o); });
+          E[i * GRAD_ROW + c] = o;
+        });
+      });
+    }
     settle_inputs();                                       // the next inputs have landed before any store is issued
     IDS_WAVE_SYNC();                                       // every lane has left the tile
     if (!has_next) break;                                  // uniform

@@ -1881,52 +1881,12 @@ __global__ __launch_bounds__(64 * MINV_COLS_W, MINV_COLS_MIN_WAVES) void minv_co
 
 #endif  // RBD_NEED_MINV
 
-#ifdef RBD_NEED_FD
-// out[b] = -Minv[b] dc_du[b]  ([n, n] x [n, 2n]) for robots without a fused -Minv epilogue.
-// One thread per (configuration, output column): its column of dc_du stays in registers (n coalesced
-// loads), the block's Minv matrices are staged in LDS once and read as broadcasts, so global traffic
-// is exactly Minv + dc_du in, dqdd_du out.
-constexpr int FDA_CPB = (256 / N) > 0 ? 256 / N : 1;     // configurations per block: N threads each, a thread owns columns c and c + N
-template <class T>
-__global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict__ Minv, const T* __restrict__ dcdu,
-                                                            long long B, T* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* Ml = reinterpret_cast<T*>(smem_raw);                            // [FDA_CPB][N * N]
-  const long long cfg0 = (long long)blockIdx.x * FDA_CPB;
-  const long long rem = B - cfg0;
-  const int nvalid = rem < FDA_CPB ? (int)rem : FDA_CPB;
-  {
-    const T* src = Minv + cfg0 * (N * N);
-    for (int g = threadIdx.x; g < nvalid * N * N; g += 256) Ml[g] = src[g];
-  }
-  __syncthreads();
-  const int cl = threadIdx.x / N;
-  const int c = threadIdx.x - cl * N;
-  if (cl >= nvalid) return;
-  const T* D = dcdu + (cfg0 + cl) * (2 * N * N);
-  T* O = out + (cfg0 + cl) * (2 * N * N);
-  const T* M = Ml + cl * (N * N);
-  // the dq and the dqd column of the same index share every Minv element read from LDS (the kernel is bound by
-  // those reads: one per FMA with a single column per thread)
-  T d0[N], d1[N];
-  sfor<0, N>([&](auto K) { constexpr int k = decltype(K)::value; d0[k] = D[k * 2 * N + c]; d1[k] = D[k * 2 * N + N + c]; });
-#pragma clang loop unroll(disable)
-  for (int i = 0; i < N; ++i) {
-    T o0 = T(0), o1 = T(0);
-    sfor<0, N>([&](auto K) {
-      constexpr int k = decltype(K)::value;
-      const T m = M[i * N + k];
-      o0 = fma_(-m, d0[k], o0);
-      o1 = fma_(-m, d1[k], o1);
-    });
-    O[i * 2 * N + c] = o0;
-    O[i * 2 * N + N + c] = o1;
-  }
-}
-
-#endif  // RBD_NEED_FD
-
 }  // namespace rbdk
+#ifdef RBD_NEED_FD
+// out[b] = -Minv[b] dc_du[b]  ([n, n] x [n, 2n]) for robots whose gradient kernel cannot fold the product into its
+// epilogue: neg_mm_kernel<T, N> (C consecutive configurations per block, in and out as flat 16-byte copies through LDS)
+#include "rbd_negmm.h"
+#endif  // RBD_NEED_FD
 #include "rbd_minv_lane.h"     // also defines MINV_LANE_OK, which sizes the workspaces (every unit)
 #ifdef RBD_NEED_MINV
 #include "rbd_minv_ia8.h"
@@ -1937,6 +1897,7 @@ __global__ __launch_bounds__(256) void fd_grad_apply_kernel(const T* __restrict_
 #endif
 #ifdef RBD_NEED_FD
 #include "rbd_aba.h"
+#include "rbd_fd_chain.h"
 #endif
 #ifdef RBD_NEED_PASS
 #include "rbd_passes.h"
@@ -2306,7 +2267,7 @@ int idsva_launch(const T* q, const T* qd, const T* qdd, T gravity, int use_dampi
     if ((rc = resident_blocks(kp, 64, lds, &resident)) != 0) return rc;
     const int64_t blocks = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL(kp, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, qdd, gravity, use_damping,
-                       (long long)B, c, dc_du);
+                       (long long)B, c, dc_du, (const T*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_rnea_grad launch");
     return 0;
@@ -2521,7 +2482,7 @@ int grad_kernel_name(int64_t B, char* buf, size_t len) {
   else if (tree) std::snprintf(buf, len, "rnea_grad_tree_kernel<%s,true>", t);
   else if (grad_chain_kernel<T>()) {
 #ifndef RBD_EXP_NO_PIPE
-    if (IDS_PIPE_OK && sizeof(T) == 4) std::snprintf(buf, len, "rnea_grad_idsva_pipe_kernel<%s,true>", t);
+    if (IDS_PIPE_OK && sizeof(T) == 4) std::snprintf(buf, len, "rnea_grad_idsva_pipe_kernel<%s,true,false>", t);
     else
 #endif
     std::snprintf(buf, len, "rnea_grad_idsva_kernel<%s,true,false>", t);
@@ -2687,7 +2648,9 @@ struct FdWorkspace {
     size_t o = 0;
     off_minv_ws = o; o += align16((size_t)B * MINV_WS_PER_CFG * sizeof(T));
     off_c = o;       o += align16((size_t)B * N * sizeof(T));
-    off_minv = o;    o += align16((size_t)B * N * N * sizeof(T));
+    // (one-chain fp32 robots keep the packed upper triangle of Minv here, in whole tiles: rbd_fd_chain.h)
+    const size_t dense = (size_t)B * N * N, packed = (size_t)((B + 63) / 64) * 64 * (N * (N + 1) / 2);
+    off_minv = o;    o += align16((dense > packed ? dense : packed) * sizeof(T));
     off_qdd = o;     o += align16((size_t)B * N * sizeof(T));
     off_dcdu = o;    o += GRAD_ACC_IN_REGS ? 0 : align16((size_t)B * 2 * N * N * sizeof(T));
     total = o;
@@ -2717,6 +2680,39 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   T* Mi = reinterpret_cast<T*>(w + L.off_minv);
   T* qdd_buf = qdd ? qdd : reinterpret_cast<T*>(w + L.off_qdd);
   int rc;
+  if constexpr (fd_chain_ok<T>() && grad_chain_kernel<T>()) {
+    // one chain (rbd_fd_chain.h): fd_pre_kernel (bias force, Minv, qdd in one lane; Minv's upper triangle to a lane-major
+    // workspace), then the world-frame chain gradient kernel with the -Minv product on its finished entries -- the
+    // software-pipelined kernel in fp32 where it applies
+    const int64_t tiles = (B + 63) / 64;
+    if (tiles > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
+    hipLaunchKernelGGL(fd_pre_kernel<T>, dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, q, qd, u, gravity, (long long)B, qdd_buf, Mi);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad (fd_pre_kernel) launch");
+    const size_t lds = sizeof(T) * (size_t)64 * IDS_TS;
+    int resident = 0;
+#ifndef RBD_EXP_NO_PIPE
+    if constexpr (IDS_PIPE_OK && sizeof(T) == 4) {
+      auto kp = rnea_grad_idsva_pipe_kernel<T, true, true>;
+      if ((rc = ensure_lds(kp, lds)) != 0) return rc;
+      if ((rc = resident_blocks(kp, 64, lds, &resident)) != 0) return rc;
+      const int64_t blocks = tiles < resident ? tiles : resident;
+      hipLaunchKernelGGL(kp, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)qdd_buf, gravity, 0, (long long)B,
+                         (T*)nullptr, dqdd_du, (const T*)Mi);
+    } else
+#endif
+    {
+      auto k = rnea_grad_idsva_kernel<T, true, true>;
+      if ((rc = ensure_lds(k, lds)) != 0) return rc;
+      if ((rc = resident_blocks(k, 64, lds, &resident)) != 0) return rc;
+      const int64_t blocks = tiles < resident ? tiles : resident;
+      hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, qd, (const T*)qdd_buf, gravity, 0, (long long)B,
+                         (T*)nullptr, dqdd_du, (const T*)Mi);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad (gradient kernel) launch");
+    return 0;
+  } else {
   // c = rnea(q, qd) with qdd = None (:1372), c-only kernel of the RNEA unit
   if constexpr (sizeof(T) == 4) rc = rbd_rnea_f32((const float*)q, (const float*)qd, nullptr, (float)gravity, B, (float*)c, nullptr, nullptr, nullptr, stream);
   else rc = rbd_rnea_f64((const double*)q, (const double*)qd, nullptr, (double)gravity, B, (double*)c, nullptr, nullptr, nullptr, stream);
@@ -2727,9 +2723,7 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
   if (rc != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
-  if constexpr (grad_chain_fdg<T>() && grad_max_rows() == N) {
-    return idsva_launch<T, true, true>(q, qd, (const T*)qdd_buf, gravity, 0, B, (T*)nullptr, dqdd_du, stream, (const T*)Mi);
-  } else if constexpr (GRAD_ACC_IN_REGS) {
+  if constexpr (GRAD_ACC_IN_REGS) {
     return rnea_grad_launch1<T, true, true>(q, qd, qdd_buf, gravity, 0, B, nullptr, dqdd_du, stream, Mi);
   } else {
     T* dc = reinterpret_cast<T*>(w + L.off_dcdu);
@@ -2737,15 +2731,15 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     if constexpr (sizeof(T) == 4) rc = rbd_rnea_grad_f32((const float*)q, (const float*)qd, (const float*)qdd_buf, (float)gravity, 0, B, nullptr, (float*)dc, stream);
     else rc = rbd_rnea_grad_f64((const double*)q, (const double*)qd, (const double*)qdd_buf, (double)gravity, 0, B, nullptr, (double*)dc, stream);
     if (rc != 0) return rc;
-    static_assert(2 * N <= 256, "fd_grad_apply_kernel: one block must hold a configuration's 2n columns");
-    const int64_t ablocks = (B + FDA_CPB - 1) / FDA_CPB;
+    constexpr int MMC = negmm_cfgs<T, N>();
+    const int64_t ablocks = (B + MMC - 1) / MMC;
     if (ablocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
-    if ((rc = ensure_lds(fd_grad_apply_kernel<T>, sizeof(T) * FDA_CPB * N * N)) != 0) return rc;
-    hipLaunchKernelGGL(fd_grad_apply_kernel<T>, dim3((unsigned)ablocks), dim3(256), sizeof(T) * FDA_CPB * N * N, (hipStream_t)stream,
+    hipLaunchKernelGGL((neg_mm_kernel<T, N>), dim3((unsigned)ablocks), dim3(negmm_threads<T, N>()), 0, (hipStream_t)stream,
                        (const T*)Mi, (const T*)dc, (long long)B, dqdd_du);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad apply launch");
     return 0;
+  }
   }
 }
 #endif  // RBD_NEED_FD
