@@ -407,8 +407,13 @@ def main():
             ms = time_extra_ms(lambda: rbd.aba(q, qd, qdd), 10, 2)
             extra["iiwa_aba_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
                                                    "alg_GBps": Bq * 4 * 7 * 4 / (ms * 1e-3) / 1e9}
+            # forward_dynamics_grad (what MPC consumers call): algorithmic bytes (3 n + 2 n^2) s per evaluation
+            # (q, qd, u in; [qdd_dq | qdd_dqd] out); two launches for a chain: fd_pre_kernel + the chain gradient kernel with the
+            # -Minv epilogue (rbd_fd_chain.h)
             ms = time_extra_ms(lambda: rbd.forward_dynamics_grad(q, qd, qdd), 10, 2)
-            extra["iiwa_forward_dynamics_grad_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3)}
+            extra["iiwa_forward_dynamics_grad_B%d_f32_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
+                                                                    "alg_GBps": Bq * (3 * 7 + 2 * 49) * 4 / (ms * 1e-3) / 1e9,
+                                                                    "kernels": "fd_pre_kernel<float> + rnea_grad_idsva_pipe_kernel<float,true,true>"}
             try:
                 # the reference's own arithmetic (fp64) on the headline robot, and the first-use path (the model-handle
                 # library, include/rbd_generic.h: no per-robot compilation) on one rank's share of the batch
@@ -418,6 +423,10 @@ def main():
                 extra["iiwa_rnea_grad_B%d_f64_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
                                                              "alg_GBps": Bq * (21 + 98) * 8 / (ms * 1e-3) / 1e9,
                                                              "kernel": rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 8, Bq)}
+                ms = time_extra_ms(lambda: rbd.forward_dynamics_grad(q64, qd64, qdd64), 5, 2)
+                extra["iiwa_forward_dynamics_grad_B%d_f64_api" % Bq] = {"ms_per_call": ms, "evals_per_s": Bq / (ms * 1e-3),
+                                                                        "alg_GBps": Bq * (3 * 7 + 2 * 49) * 8 / (ms * 1e-3) / 1e9,
+                                                                        "kernels": "fd_pre_kernel<double> + rnea_grad_idsva_kernel<double,true,true>"}
                 del q64, qd64, qdd64, dc64
                 gen = RBDReference(robot, build=False, generic="only")
                 Bg = 131072
@@ -488,6 +497,10 @@ def main():
                                                        "alg_GBps": 16384 * (4 * 30 + 2 * 900) * 8 / (ms * 1e-3) / 1e9,
                                                        "kernel": ra._lib.kernel_name(1, 8, 16384)}
                 del qa8, qda8, qdda8
+                ms = time_extra_ms(lambda: ra.forward_dynamics_grad(qa, qda, qdda), 10, 2)
+                extra["atlas_forward_dynamics_grad_B16384_f32_api"] = {
+                    "ms_per_call": ms, "evals_per_s": 16384 / (ms * 1e-3), "alg_GBps": 16384 * (3 * 30 + 2 * 900) * 4 / (ms * 1e-3) / 1e9,
+                    "kernels": "rnea_kernel + minv_fused_kernel + rnea_grad_tree_kernel + neg_mm_kernel<float,30>"}
                 rq = RBDReference(quadruped_like(), build=False)
                 qq, qdq, qddq = make_inputs(65536, 12, 4, dev, torch.float64)
                 ms1 = time_extra_ms(lambda: rq.rnea_grad(qq, qdq, qddq, return_c=True), 10, 2)
@@ -495,6 +508,10 @@ def main():
                 extra["cfg4_quadruped_rnea_grad+minv_B65536_f64"] = {
                     "ms_rnea_grad": ms1, "ms_minv": ms2, "evals_per_s": 65536 / ((ms1 + ms2) * 1e-3),
                     "alg_GBps": 65536 * 3840 / ((ms1 + ms2) * 1e-3) / 1e9}
+                ms = time_extra_ms(lambda: rq.forward_dynamics_grad(qq, qdq, qddq), 10, 2)
+                extra["quadruped_forward_dynamics_grad_B65536_f64_api"] = {
+                    "ms_per_call": ms, "evals_per_s": 65536 / (ms * 1e-3), "alg_GBps": 65536 * (3 * 12 + 2 * 144) * 8 / (ms * 1e-3) / 1e9,
+                    "kernels": "rnea_kernel + minv_lane_kernel + rnea_grad_kernel<double,true,true> (one block per leg, -Minv epilogue)"}
                 # floating base: a 13-body trunk + four legs, nv = 18, fp32
                 from rbdreference_amd import floating_quadruped_like
                 rf = RBDReference(floating_quadruped_like(), build=False)
@@ -508,6 +525,10 @@ def main():
                     "ms_rnea_cvaf": t1, "alg_GBps_rnea": Bf * (4 * nvf + 18 * nbf) * 4 / (t1 * 1e-3) / 1e9,
                     "ms_minv": t2, "alg_GBps_minv": Bf * (nvf + nvf * nvf) * 4 / (t2 * 1e-3) / 1e9,
                     "ms_rnea_grad": t3, "alg_GBps_rnea_grad": Bf * (4 * nvf + 2 * nvf * nvf) * 4 / (t3 * 1e-3) / 1e9}
+                t4 = time_extra_ms(lambda: rf.forward_dynamics_grad(qf, qdf, qddf), 5, 1)
+                extra["floating_quadruped_forward_dynamics_grad_B65536_f32_api"] = {
+                    "ms_per_call": t4, "evals_per_s": Bf / (t4 * 1e-3), "alg_GBps": Bf * (3 * nvf + 2 * nvf * nvf) * 4 / (t4 * 1e-3) / 1e9,
+                    "kernels": "rnea_fbw + minv_fbm + fb_apply + rnea_grad_fbw + neg_mm_kernel<float,18>"}
             except Exception as e:  # the headline line must still be printed
                 extra["error"] = repr(e)
             try:
@@ -544,6 +565,9 @@ def main():
                         "atlas_rnea_grad_B16384_f32": ("", ["rnea_grad_tree_kernel<float,true>"], 16384 * (4 * 30 + 2 * 900) * 4),
                         "atlas_rnea_grad_B16384_f64": ("", ["rnea_grad_tree_ws_kernel<double,true>"], 16384 * (4 * 30 + 2 * 900) * 8),
                         "cfg4_quadruped_rnea_grad+minv_B65536_f64": ("", ["rnea_grad_kernel<double,true,false>", "minv_lane_kernel<double>"], 65536 * 3840),
+                        "iiwa_forward_dynamics_grad_B1048576_f32_api": ("", ["fd_pre_kernel<float>", "rnea_grad_idsva_pipe_kernel<float,true,true>"], (1 << 20) * (3 * 7 + 2 * 49) * 4),
+                        "atlas_forward_dynamics_grad_B16384_f32_api": ("", ["rnea_kernel<float,false,false>", "minv_fused_kernel<float>", "rnea_grad_tree_kernel<float,true>", "neg_mm_kernel<float,30>"], 16384 * (3 * 30 + 2 * 900) * 4),
+                        "floating_quadruped_forward_dynamics_grad_B65536_f32_api": ("", ["rnea_fbw_kernel<float,false,0>", "minv_fbm_kernel<float>", "fb_apply_kernel<float>", "rnea_grad_fbw_kernel<float,true>", "neg_mm_kernel<float,18>"], 65536 * (3 * nvq + 2 * nvq * nvq) * 4),
                     }
                     fbq = {"_rnea": (["rnea_fbw_kernel<float,true,0>"], 65536 * (4 * nvq + 18 * nbq) * 4),
                            "_minv": (["minv_fbm_kernel<float>"], 65536 * (nvq + nvq * nvq) * 4),

@@ -113,6 +113,41 @@ int rbd_g_forward_dynamics_grad_f32(const rbd_model*, const float* q, const floa
 int rbd_g_forward_dynamics_grad_f64(const rbd_model*, const double* q, const double* qd, const double* u, double gravity, int64_t B,
                                     double* qdd, double* dqdd_du, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The per-pass surface the reference designates for accelerator testing (README.md:19) and crba, for FIXED-base models
+ * (a floating-base model is refused with RBD_G_ERR_UNSUPPORTED: the reference's own crba raises for one, RBDReference.py:1063,
+ * and its floating-base pass layouts are served by the robot's own library, include/rbd_hip.h).  Arguments, layouts and
+ * in-place behaviour are those of the same-named entry points of include/rbd_hip.h -- v, a, f [B, 6, n]; dv, da, df
+ * [B, 6, n, n] (element [b, r, c, i]); F [B, n, 6, n]; Dinv holds D -- with the model handle in front:
+ *   rnea_fpass (RBDReference.py:559-598, local f)        rnea_bpass (:600-621, f accumulated IN PLACE)
+ *   rnea_grad_fpass_dq (:1127-1187)                      rnea_grad_fpass_dqd (:1189-1255)
+ *   rnea_grad_bpass_dq (:1257-1297, df IN PLACE, literal fxS term)   rnea_grad_bpass_dqd (:1299-1343, damping)
+ *   minv_bpass (:630-735)                                minv_fpass (:737-783, whole rows of Minv IN PLACE, F rebuilt)
+ *   crba (:1091-1124)
+ * One configuration per lane, the literal recurrences with the output tensors as working storage: they exist so that an
+ * accelerator port can be compared pass by pass against the reference on a machine WITHOUT a compiler. */
+int rbd_g_rnea_fpass_f32(const rbd_model*, const float* q, const float* qd, const float* qdd, float gravity, int64_t B, float* v, float* a, float* f, void* stream);
+int rbd_g_rnea_bpass_f32(const rbd_model*, const float* q, float* f, int64_t B, float* c, void* stream);
+int rbd_g_rnea_grad_fpass_dq_f32(const rbd_model*, const float* q, const float* qd, const float* v, const float* a, float gravity, int64_t B,
+                                  float* dv_dq, float* da_dq, float* df_dq, void* stream);
+int rbd_g_rnea_grad_fpass_dqd_f32(const rbd_model*, const float* q, const float* qd, const float* v, int64_t B, float* dv_dqd, float* da_dqd,
+                                   float* df_dqd, void* stream);
+int rbd_g_rnea_grad_bpass_dq_f32(const rbd_model*, const float* q, const float* f, float* df_dq, int64_t B, float* dc_dq, void* stream);
+int rbd_g_rnea_grad_bpass_dqd_f32(const rbd_model*, const float* q, float* df_dqd, int use_damping, int64_t B, float* dc_dqd, void* stream);
+int rbd_g_minv_bpass_f32(const rbd_model*, const float* q, int64_t B, float* Minv, float* F, float* U, float* Dinv, void* stream);
+int rbd_g_minv_fpass_f32(const rbd_model*, const float* q, int64_t B, float* Minv, float* F, const float* U, const float* Dinv, void* stream);
+int rbd_g_crba_f32(const rbd_model*, const float* q, int64_t B, float* H, void* stream);
+int rbd_g_rnea_fpass_f64(const rbd_model*, const double* q, const double* qd, const double* qdd, double gravity, int64_t B, double* v, double* a, double* f, void* stream);
+int rbd_g_rnea_bpass_f64(const rbd_model*, const double* q, double* f, int64_t B, double* c, void* stream);
+int rbd_g_rnea_grad_fpass_dq_f64(const rbd_model*, const double* q, const double* qd, const double* v, const double* a, double gravity, int64_t B,
+                                  double* dv_dq, double* da_dq, double* df_dq, void* stream);
+int rbd_g_rnea_grad_fpass_dqd_f64(const rbd_model*, const double* q, const double* qd, const double* v, int64_t B, double* dv_dqd, double* da_dqd,
+                                   double* df_dqd, void* stream);
+int rbd_g_rnea_grad_bpass_dq_f64(const rbd_model*, const double* q, const double* f, double* df_dq, int64_t B, double* dc_dq, void* stream);
+int rbd_g_rnea_grad_bpass_dqd_f64(const rbd_model*, const double* q, double* df_dqd, int use_damping, int64_t B, double* dc_dqd, void* stream);
+int rbd_g_minv_bpass_f64(const rbd_model*, const double* q, int64_t B, double* Minv, double* F, double* U, double* Dinv, void* stream);
+int rbd_g_minv_fpass_f64(const rbd_model*, const double* q, int64_t B, double* Minv, double* F, const double* U, const double* Dinv, void* stream);
+int rbd_g_crba_f64(const rbd_model*, const double* q, int64_t B, double* H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1006,10 +1006,21 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   const long long rem = B - cfg0;
   const int nvalid = rem < CFGS ? (int)rem : CFGS;
   const long long b = cfg0 + (slot < nvalid ? slot : nvalid - 1);
-  T* mtile = tile + CFGS * GRAD_TS;      // FDG: [CFGS][N*N] copy of Minv
+  T* mtile = tile + CFGS * GRAD_TS;      // FDG: [CFGS][N*N] copy of Minv; with one block per group: [CFGS][FDG_MS] copy of that group's rows
+  constexpr int FDG_MS = (grad_max_rows() * N) | 1;      // odd stride: the lanes' rows start in different banks
   if constexpr (FDG) {
-    const T* msrc = minv_in + cfg0 * (N * N);
-    for (int g = lane; g < nvalid * N * N; g += NT) mtile[g] = msrc[g];
+    // one block for all groups: the block's whole Minv rows; one block per group (split): only that group's rows, below
+    if (split <= 1) {
+      const T* msrc = minv_in + cfg0 * (N * N);
+      // batches of 16 loads in flight, then their LDS writes (not load -> write per iteration: one HBM latency each)
+      constexpr int NL = (CFGS * N * N + NT - 1) / NT;
+      sfor<0, (NL + 15) / 16>([&](auto C_) {
+        constexpr int c0 = decltype(C_)::value * 16, c1 = c0 + 16 < NL ? c0 + 16 : NL;
+        T mb[16];
+        sfor<c0, c1>([&](auto I_) { constexpr int i_ = decltype(I_)::value; const int g = lane + i_ * NT; mb[i_ - c0] = msrc[g < nvalid * N * N ? g : 0]; });
+        sfor<c0, c1>([&](auto I_) { constexpr int i_ = decltype(I_)::value; const int g = lane + i_ * NT; if (g < CFGS * N * N) mtile[g] = mb[i_ - c0]; });
+      });
+    }
   }
 
   // Independent roots (the quadruped's four legs) are processed one after the other -- loads, RNEA
@@ -1049,6 +1060,27 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   // serialized HBM round trips); the NEXT group's loads are issued before this group's passes, so
   // their latency hides behind a whole group of arithmetic.
   if (gsel >= 0 || rt == grp_first()) load_group(Rt);
+  if constexpr (FDG) {
+    if (gsel >= 0) {          // this block's group only: rows row0 .. row0 + rows - 1 of every configuration's Minv (rows * N contiguous scalars)
+      constexpr int RN = rows * N;
+      const T* msrc = minv_in + cfg0 * (N * N) + row0 * N;
+      // every load issued before the first LDS write (a load -> write loop costs one HBM latency per iteration: 18 of them here)
+      constexpr int NL = (CFGS * RN + NT - 1) / NT;
+      T mb[NL];
+      sfor<0, NL>([&](auto I_) {
+        constexpr int i_ = decltype(I_)::value;
+        const int g = lane + i_ * NT;
+        const int cfg = g / RN, r2 = g - cfg * RN;
+        mb[i_] = msrc[g < nvalid * RN ? cfg * (N * N) + r2 : 0];
+      });
+      sfor<0, NL>([&](auto I_) {
+        constexpr int i_ = decltype(I_)::value;
+        const int g = lane + i_ * NT;
+        const int cfg = g / RN, r2 = g - cfg * RN;
+        if (g < CFGS * RN) mtile[cfg * FDG_MS + r2] = mb[i_];
+      });
+    }
+  }
   pair_trig<rt, 0>(isqd, qv, tr);
   if constexpr (grp_next(rt) >= 0) {
     if (gsel < 0) load_group(std::integral_constant<int, grp_next(rt) >= 0 ? grp_next(rt) : 0>{});
@@ -1174,7 +1206,8 @@ __global__ __launch_bounds__(2 * grad_cfgs<T>(), grad_min_waves<T>()) void rnea_
   if constexpr (FDG) {
     // out[i][c] = - sum_k Minv[i][k] dc[k][c]  (:1382-1383); Minv and dc are block-diagonal over groups
     __syncthreads();                       // mtile is complete (written by other lanes at the start)
-    const T* mt = mtile + (slot < nvalid ? slot : 0) * (N * N);
+    // (split: the tile holds rows row0 .. of this group only, stride FDG_MS; mt[i * N + k] below then addresses row i - row0)
+    const T* mt = gsel >= 0 ? mtile + (slot < nvalid ? slot : 0) * FDG_MS - row0 * N : mtile + (slot < nvalid ? slot : 0) * (N * N);
     sfor<0, N>([&](auto C) {
       constexpr int cc = decltype(C)::value;
       if constexpr (!grp_has(rt, cc)) {
@@ -2227,14 +2260,18 @@ int rnea_grad_launch1(const T* q, const T* qd, const T* qdd, T gravity, int use_
   const int64_t blocks = (B + CFGS - 1) / CFGS;
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_rnea_grad: B too large");
   if ((reinterpret_cast<uintptr_t>(dc_du) & 15u) != 0) return fail(RBD_ERR_ARG, "rbd_rnea_grad: dc_du must be 16-byte aligned");
-  const size_t lds = sizeof(T) * ((size_t)CFGS * GRAD_TS + (FDG ? (size_t)CFGS * N * N : 0));
+  // (with one block per group the Minv tile holds that group's rows only: 55 -> 28 KB for the quadruped in fp64, i.e. five
+  // 64-thread blocks per CU instead of two)
+  constexpr bool SPLIT = GRAD_PER_ROOT && n_groups() > 1;
+  const size_t lds = sizeof(T) * ((size_t)CFGS * GRAD_TS + (FDG ? (size_t)CFGS * (SPLIT ? (size_t)((grad_max_rows() * N) | 1) : (size_t)(N * N)) : 0));
   if (lds > 160 * 1024) return fail(RBD_ERR_UNSUPPORTED, "rbd_rnea_grad: output tile does not fit LDS for this robot size");
   auto k = rnea_grad_kernel<T, HAS_QDD, FDG>;
   int rc;
   if ((rc = ensure_lds(k, lds)) != 0) return rc;
-  // independent root subtrees get their own blocks (not with the fused -Minv epilogue, whose Minv
-  // tile is shared by the groups)
-  const int split = (!FDG && GRAD_PER_ROOT && n_groups() > 1) ? n_groups() : 1;
+  // independent root subtrees get their own blocks -- also with the fused -Minv epilogue (round 4): Minv and dc_du are
+  // block-diagonal over the groups, so a group's block stages that group's Minv rows only (the quadruped's fp64
+  // forward_dynamics_grad gradient leg: 151 us with every leg in one block, serial)
+  const int split = (GRAD_PER_ROOT && n_groups() > 1) ? n_groups() : 1;
 #ifdef RBD_EXP_NO_XCD_MAP
   const int64_t grid = blocks * split;
 #else

@@ -214,7 +214,7 @@ GDEV void body_X(const DevModel<T>* __restrict__ m, int i, const RneaState<T, NM
 // (:612), body i >= 1 owns index i + 5.
 template <bool FB, class T, int NMAX>
 GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, const T* qd, const T* qdd, T grav,
-                      RneaState<T, NMAX>& st, T* co, T* vo, T* ao, T* fo) {
+                      RneaState<T, NMAX>& st, T* co, T* vo, T* ao, T* fo, bool fpass_only = false) {
   constexpr int OFF = FB ? 5 : 0;
   for (int i = 0; i < n; ++i) {
     T X[36], v[6], a[6], vJ[6], t[6];
@@ -267,8 +267,10 @@ GDEV void rnea_config(const DevModel<T>* __restrict__ m, int n, const T* q, cons
       st.v[i][r] = v[r]; st.a[i][r] = a[r]; st.f[i][r] = Ia[r] + w[r];
       if (vo) vo[r * n + i] = v[r];
       if (ao) ao[r * n + i] = a[r];
+      if (fpass_only && fo) fo[r * n + i] = Ia[r] + w[r];                                    // rnea_fpass returns the LOCAL force (:595-598)
     }
   }
+  if (fpass_only) return;
   for (int i = n - 1; i >= 0; --i) {
     T f[6];
 #pragma unroll
@@ -928,6 +930,352 @@ int hip_fail(hipError_t e, const char* what) {
   return (int)e;
 }
 
+
+// =====================================================================================================================
+// The per-pass surface the reference designates for accelerator testing (README.md:19), fixed base: every pass as the
+// LITERAL recurrence, one configuration per lane, with the pass's own output tensors as working storage (a lane reads
+// back what it wrote for the parent body: rows of different configurations never meet).  Layouts as the reference
+// returns them, batch outermost: v, a, f [B, 6, n]; dv, da, df [B, 6, n, n] (element [b, r, c, i]); F [B, n, 6, n].
+// These kernels exist to be compared pass by pass with the reference; they move its O(n^2) six-vectors through HBM by
+// definition.
+// =====================================================================================================================
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_rnea_fpass_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, const T* __restrict__ qd,
+                                                          const T* __restrict__ qdd, T grav, long long B, T* __restrict__ v, T* __restrict__ a,
+                                                          T* __restrict__ f) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  RneaState<T, NMAX> st;
+  rnea_config<false, T, NMAX>(m, n, q + b * n, qd + b * n, qdd ? qdd + b * n : nullptr, grav, st, nullptr, v + b * 6 * n, a + b * 6 * n,
+                              f + b * 6 * n, true);
+}
+// rnea_bpass (:600-621): c = S^T f, f accumulated child -> parent IN PLACE
+template <class T>
+__global__ void __launch_bounds__(64) g_rnea_bpass_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, T* __restrict__ f,
+                                                          long long B, T* __restrict__ c) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T* fb = f + b * 6 * n;
+  for (int i = n - 1; i >= 0; --i) {
+    T fi[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) fi[r] = fb[r * n + i];
+    c[b * n + i] = dot6g(m->S[i], fi);                                                      // :612
+    const int p = m->parent[i];
+    if (p >= 0) {
+      T f1, f2, X[36], t[6];
+      joint_fun(m->jtype[i], q[b * n + i], f1, f2);
+      build_X(m, i, f1, f2, X);
+      mtv(X, fi, t);                                                                        // :618-619
+#pragma unroll
+      for (int r = 0; r < 6; ++r) fb[r * n + p] += t[r];
+    }
+  }
+}
+// rnea_grad_fpass_dq (DQ, :1127-1187) / rnea_grad_fpass_dqd (:1189-1255)
+template <class T, bool DQ>
+__global__ void __launch_bounds__(64) g_grad_fpass_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, const T* __restrict__ qd,
+                                                          const T* __restrict__ v, const T* __restrict__ a, T grav, long long B,
+                                                          T* __restrict__ dv, T* __restrict__ da, T* __restrict__ df) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  const T* vb = v + b * 6 * n;
+  const T* ab = DQ ? a + b * 6 * n : nullptr;
+  T* dvb = dv + b * 6LL * n * n;
+  T* dab = da + b * 6LL * n * n;
+  T* dfb = df + b * 6LL * n * n;
+  for (int i = 0; i < n; ++i) {
+    const int p = m->parent[i];
+    T f1, f2, X[36], S[6], vi[6], Iv[6], seed_v[6], seed_a[6];
+    joint_fun(m->jtype[i], q[b * n + i], f1, f2);
+    build_X(m, i, f1, f2, X);
+    const T qdi = qd[b * n + i];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { S[r] = m->S[i][r]; vi[r] = vb[r * n + i]; }
+    mvI(m, i, vi, Iv);
+    // what column i receives at body i: dq -- crm(X v_p) S into dv (:1159), crm(X a_p | X a_grav) S into da (:1173-1175);
+    // dqd -- S into dv (:1231), crm(v_i) S into da (:1243)
+    if (DQ) {
+      T vp[6], ap[6], xv[6], xa[6];
+      if (p >= 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { vp[r] = vb[r * n + p]; ap[r] = ab[r * n + p]; }
+        mv(X, vp, xv);
+        mv(X, ap, xa);
+        crm_mul(xv, S, seed_v);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { xa[r] = X[r * 6 + 5] * (-grav); seed_v[r] = T(0); }
+      }
+      crm_mul(xa, S, seed_a);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) seed_v[r] = S[r];
+      crm_mul(vi, S, seed_a);
+    }
+    for (int c = 0; c < n; ++c) {
+      T dvc[6], dac[6], t[6], dfc[6];
+      if (p >= 0) {
+        T dvp[6], dap[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { dvp[r] = dvb[(r * n + c) * n + p]; dap[r] = dab[(r * n + c) * n + p]; }
+        mv(X, dvp, dvc);                                                                    // :1158 / :1230
+        mv(X, dap, dac);                                                                    // :1163 / :1234
+      } else {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { dvc[r] = T(0); dac[r] = T(0); }
+      }
+      if (c == i) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) dvc[r] += seed_v[r];
+      }
+      crm_mul(dvc, S, t);                                                                   // :1164-1170 / :1235-1240
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dac[r] = fma(qdi, t[r], dac[r]);
+      if (c == i) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) dac[r] += seed_a[r];
+      }
+      df_of(m, i, vi, Iv, dvc, dac, dfc);                                                   // :1177-1185 / :1245-1252
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        dvb[(r * n + c) * n + i] = dvc[r];
+        dab[(r * n + c) * n + i] = dac[r];
+        dfb[(r * n + c) * n + i] = dfc[r];
+      }
+    }
+  }
+}
+// rnea_grad_bpass_dq (DQ, :1257-1297: f is the ACCUMULATED rnea force, the literal fxS term) / rnea_grad_bpass_dqd
+// (:1299-1343, damping); df accumulated child -> parent IN PLACE
+template <class T, bool DQ>
+__global__ void __launch_bounds__(64) g_grad_bpass_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, const T* __restrict__ f,
+                                                          T* __restrict__ df, int damp, long long B, T* __restrict__ dc) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T* dfb = df + b * 6LL * n * n;
+  T* dcb = dc + b * (long long)n * n;
+  for (int i = n - 1; i >= 0; --i) {
+    const int p = m->parent[i];
+    T f1, f2, X[36], S[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+    if (p >= 0) {
+      joint_fun(m->jtype[i], q[b * n + i], f1, f2);
+      build_X(m, i, f1, f2, X);
+    }
+    for (int c = 0; c < n; ++c) {
+      T dfc[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dfc[r] = dfb[(r * n + c) * n + i];
+      dcb[i * n + c] = dot6g(S, dfc) + ((!DQ && damp && c == i) ? m->damping[i] : T(0));    // :1284 / :1325, :1336-1341
+      if (p >= 0) {
+        T t[6];
+        mtv(X, dfc, t);                                                                     // :1291 / :1331
+#pragma unroll
+        for (int r = 0; r < 6; ++r) dfb[(r * n + c) * n + p] += t[r];
+      }
+    }
+    if (DQ && p >= 0) {                                                                     // :1292-1294: df[:, i, p] += X^T fxS(S, f_i), fxS = -crm(f) S
+      T fi[6], w[6], t[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) fi[r] = f[b * 6 * n + r * n + i];
+      crm_mul(fi, S, w);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) w[r] = -w[r];
+      mtv(X, w, t);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dfb[(r * n + i) * n + p] += t[r];
+    }
+  }
+}
+// minv_bpass (:630-735) -> (Minv, F, U, Dinv = D)
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_minv_bpass_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, long long B,
+                                                          T* __restrict__ Minv, T* __restrict__ F, T* __restrict__ U, T* __restrict__ Dinv) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T* Mb = Minv + b * (long long)n * n;
+  T* Fb = F + b * 6LL * n * n;                       // F[i][r][s] = Fb[(i * 6 + r) * n + s]
+  T IA[NMAX][36];
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) IA[i][k] = m->I[i][k];                                     // :662
+    for (int s2 = 0; s2 < n; ++s2) Mb[i * n + s2] = T(0);
+    for (int k = 0; k < 6 * n; ++k) Fb[i * 6 * n + k] = T(0);
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const int p = m->parent[i];
+    T A[36], S[6], u[6];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] = IA[i][k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+    mv(A, S, u);                                                                            // :697
+    const T D = dot6g(S, u);                                                                // :698
+    const T Di = T(1) / D;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) U[(b * n + i) * 6 + r] = u[r];
+    Dinv[b * n + i] = D;
+    Mb[i * n + i] = Di;                                                                     // :700
+    T f1, f2, X[36];
+    if (p >= 0) {
+      joint_fun(m->jtype[i], q[b * n + i], f1, f2);
+      build_X(m, i, f1, f2, X);
+    }
+    for (int s2 = 0; s2 < n; ++s2) {
+      if (!((m->anc[s2] >> i) & 1ull)) continue;                                            // s2 in subtree(i) (incl. i)
+      T Fi[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Fi[r] = Fb[(i * 6 + r) * n + s2];
+      const T ms = Mb[i * n + s2] - Di * dot6g(S, Fi);                                      // :702-708
+      Mb[i * n + s2] = ms;
+      if (p >= 0) {                                                                         // :720-726
+        T t[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { Fi[r] = fma(u[r], ms, Fi[r]); Fb[(i * 6 + r) * n + s2] = Fi[r]; }
+        mtv(X, Fi, t);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Fb[(p * 6 + r) * n + s2] += t[r];
+      }
+    }
+    if (p >= 0) {                                                                           // :728-733
+      T Ia[36], XtIa[36];
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) Ia[r * 6 + cc] = A[r * 6 + cc] - u[r] * (u[cc] * Di);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          T acc = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc = fma(X[k * 6 + r], Ia[k * 6 + cc], acc);
+          XtIa[r * 6 + cc] = acc;
+        }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          T acc = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc = fma(XtIa[r * 6 + k], X[k * 6 + cc], acc);
+          IA[p][r * 6 + cc] += acc;
+        }
+    }
+  }
+}
+// minv_fpass (:737-783): whole rows of Minv updated in place (:771), F rebuilt (:774-781); Dinv holds D
+template <class T>
+__global__ void __launch_bounds__(64) g_minv_fpass_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, long long B,
+                                                          T* __restrict__ Minv, T* __restrict__ F, const T* __restrict__ U,
+                                                          const T* __restrict__ Dinv) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T* Mb = Minv + b * (long long)n * n;
+  T* Fb = F + b * 6LL * n * n;
+  for (int i = 0; i < n; ++i) {
+    const int p = m->parent[i];
+    T S[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+    if (p >= 0) {
+      T f1, f2, X[36], u[6], UX[6];
+      joint_fun(m->jtype[i], q[b * n + i], f1, f2);
+      build_X(m, i, f1, f2, X);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) u[r] = U[(b * n + i) * 6 + r];
+      mtv(X, u, UX);                                                                        // U^T X
+      const T Di = T(1) / Dinv[b * n + i];
+      for (int c = 0; c < n; ++c) {
+        T Fp[6], Fi[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Fp[r] = Fb[(p * 6 + r) * n + c];
+        const T ms = Mb[i * n + c] - Di * dot6g(UX, Fp);                                    // :771-773
+        Mb[i * n + c] = ms;
+        mv(X, Fp, Fi);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Fb[(i * 6 + r) * n + c] = fma(S[r], ms, Fi[r]);         // :774-776
+      }
+    } else {
+      for (int c = 0; c < n; ++c) {
+        const T ms = Mb[i * n + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Fb[(i * 6 + r) * n + c] = S[r] * ms;                    // :781
+      }
+    }
+  }
+}
+// crba (fixed-base branch, :1091-1124): composite inertias child -> parent, then fh = IC_i S_i up the root path
+template <class T, int NMAX>
+__global__ void __launch_bounds__(64) g_crba_kernel(const DevModel<T>* __restrict__ m, const T* __restrict__ q, long long B, T* __restrict__ H) {
+  const long long b = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int n = m->n;
+  T* Hb = H + b * (long long)n * n;
+  T IC[NMAX][36], f1[NMAX], f2[NMAX];
+  for (int i = 0; i < n; ++i) {
+    joint_fun(m->jtype[i], q[b * n + i], f1[i], f2[i]);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) IC[i][k] = m->I[i][k];
+    for (int c = 0; c < n; ++c) Hb[i * n + c] = T(0);
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const int p = m->parent[i];
+    if (p < 0) continue;
+    T X[36], A[36], XtA[36];
+    build_X(m, i, f1[i], f2[i], X);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] = IC[i][k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc = fma(X[k * 6 + r], A[k * 6 + cc], acc);
+        XtA[r * 6 + cc] = acc;
+      }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc = fma(XtA[r * 6 + k], X[k * 6 + cc], acc);
+        IC[p][r * 6 + cc] += acc;                                                           // :1101
+      }
+  }
+  for (int i = 0; i < n; ++i) {
+    T A[36], S[6], fh[6];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] = IC[i][k];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) S[r] = m->S[i][r];
+    mv(A, S, fh);                                                                           // :1109
+    Hb[i * n + i] = dot6g(S, fh);                                                           // :1110
+    int j = i;
+    while (m->parent[j] >= 0) {                                                             // :1113-1121
+      T X[36], t[6];
+      build_X(m, j, f1[j], f2[j], X);
+      mtv(X, fh, t);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) fh[r] = t[r];
+      j = m->parent[j];
+      const T h = dot6g(m->S[j], fh);
+      Hb[i * n + j] = h;
+      Hb[j * n + i] = h;
+    }
+  }
+}
+
 }  // namespace rbdg
 
 struct rbd_model {
@@ -1074,6 +1422,96 @@ int minv_host(const rbd_model* m, const T* q, long long B, int dense, T* Minv, v
 #undef CALL
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_minv launch");
+}
+
+// ---- per-pass surface + crba (fixed base only: the reference's own crba raises for a floating base, and its floating-base
+//      pass layouts are served by the per-robot libraries) --------------------------------------------------------------------
+int pass_check(const rbd_model* m, long long B, const char* who) {
+  if (int rc = check_call(m, B, who)) return rc;
+  if (m->fb) return fail(RBD_G_ERR_UNSUPPORTED, "%s: fixed-base robots only in the model-handle library (floating-base passes: the robot's own library)", who);
+  return 0;
+}
+#define RBDG_NM_DISPATCH(m, CALL)                 \
+  do {                                           \
+    const int n_ = (m)->n;                       \
+    if (n_ <= 8) { CALL(8); }                    \
+    else if (n_ <= 16) { CALL(16); }             \
+    else if (n_ <= 32) { CALL(32); }             \
+    else { CALL(64); }                           \
+  } while (0)
+template <class T>
+int rnea_fpass_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav, long long B, T* v, T* a, T* f, void* stream) {
+  if (int rc = pass_check(m, B, "rbd_g_rnea_fpass")) return rc;
+  if (!q || !qd || !v || !a || !f) return fail(RBD_G_ERR_ARG, "rbd_g_rnea_fpass: q, qd, v, a, f must not be null");
+  if (B == 0) return 0;
+  const unsigned grid = (unsigned)((B + 63) / 64);
+#define CALL(NM) hipLaunchKernelGGL((g_rnea_fpass_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, v, a, f)
+  RBDG_NM_DISPATCH(m, CALL);
+#undef CALL
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea_fpass launch");
+}
+template <class T>
+int rnea_bpass_host(const rbd_model* m, const T* q, T* f, long long B, T* c, void* stream) {
+  if (int rc = pass_check(m, B, "rbd_g_rnea_bpass")) return rc;
+  if (!q || !f || !c) return fail(RBD_G_ERR_ARG, "rbd_g_rnea_bpass: q, f, c must not be null");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL((g_rnea_bpass_kernel<T>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, f, B, c);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea_bpass launch");
+}
+template <class T, bool DQ>
+int grad_fpass_host(const rbd_model* m, const T* q, const T* qd, const T* v, const T* a, T grav, long long B, T* dv, T* da, T* df, void* stream) {
+  const char* who = DQ ? "rbd_g_rnea_grad_fpass_dq" : "rbd_g_rnea_grad_fpass_dqd";
+  if (int rc = pass_check(m, B, who)) return rc;
+  if (!q || !qd || !v || (DQ && !a) || !dv || !da || !df) return fail(RBD_G_ERR_ARG, "%s: null argument", who);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL((g_grad_fpass_kernel<T, DQ>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, v, a, grav, B, dv, da, df);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea_grad_fpass launch");
+}
+template <class T, bool DQ>
+int grad_bpass_host(const rbd_model* m, const T* q, const T* f, T* df, int damp, long long B, T* dc, void* stream) {
+  const char* who = DQ ? "rbd_g_rnea_grad_bpass_dq" : "rbd_g_rnea_grad_bpass_dqd";
+  if (int rc = pass_check(m, B, who)) return rc;
+  if (!q || (DQ && !f) || !df || !dc) return fail(RBD_G_ERR_ARG, "%s: null argument", who);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL((g_grad_bpass_kernel<T, DQ>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, f, df, damp, B, dc);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_rnea_grad_bpass launch");
+}
+template <class T>
+int minv_bpass_host(const rbd_model* m, const T* q, long long B, T* Minv, T* F, T* U, T* Dinv, void* stream) {
+  if (int rc = pass_check(m, B, "rbd_g_minv_bpass")) return rc;
+  if (!q || !Minv || !F || !U || !Dinv) return fail(RBD_G_ERR_ARG, "rbd_g_minv_bpass: null argument");
+  if (B == 0) return 0;
+  const unsigned grid = (unsigned)((B + 63) / 64);
+#define CALL(NM) hipLaunchKernelGGL((g_minv_bpass_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, Minv, F, U, Dinv)
+  RBDG_NM_DISPATCH(m, CALL);
+#undef CALL
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_minv_bpass launch");
+}
+template <class T>
+int minv_fpass_host(const rbd_model* m, const T* q, long long B, T* Minv, T* F, const T* U, const T* Dinv, void* stream) {
+  if (int rc = pass_check(m, B, "rbd_g_minv_fpass")) return rc;
+  if (!q || !Minv || !F || !U || !Dinv) return fail(RBD_G_ERR_ARG, "rbd_g_minv_fpass: null argument");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL((g_minv_fpass_kernel<T>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, Minv, F, U, Dinv);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_minv_fpass launch");
+}
+template <class T>
+int crba_host(const rbd_model* m, const T* q, long long B, T* H, void* stream) {
+  if (int rc = pass_check(m, B, "rbd_g_crba")) return rc;
+  if (!q || !H) return fail(RBD_G_ERR_ARG, "rbd_g_crba: q, H must not be null");
+  if (B == 0) return 0;
+  const unsigned grid = (unsigned)((B + 63) / 64);
+#define CALL(NM) hipLaunchKernelGGL((g_crba_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, H)
+  RBDG_NM_DISPATCH(m, CALL);
+#undef CALL
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : hip_fail(e, "rbd_g_crba launch");
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1238,5 +1676,30 @@ int rbd_g_forward_dynamics_grad_f32(const rbd_model* m, const float* q, const fl
 int rbd_g_forward_dynamics_grad_f64(const rbd_model* m, const double* q, const double* qd, const double* u, double g, int64_t B, double* qdd, double* d, void* ws, size_t wsb, void* st) {
   return rbdg::fd_host<double>(m, q, qd, u, g, B, qdd, d, true, ws, wsb, st);
 }
+
+#define RBDG_PASS_API(SFX, T)                                                                                                                    \
+  int rbd_g_rnea_fpass_##SFX(const rbd_model* m, const T* q, const T* qd, const T* qdd, T g, int64_t B, T* v, T* a, T* f, void* st) {              \
+    return rbdg::rnea_fpass_host<T>(m, q, qd, qdd, g, B, v, a, f, st);                                                                           \
+  }                                                                                                                                              \
+  int rbd_g_rnea_bpass_##SFX(const rbd_model* m, const T* q, T* f, int64_t B, T* c, void* st) { return rbdg::rnea_bpass_host<T>(m, q, f, B, c, st); } \
+  int rbd_g_rnea_grad_fpass_dq_##SFX(const rbd_model* m, const T* q, const T* qd, const T* v, const T* a, T g, int64_t B, T* dv, T* da, T* df, void* st) { \
+    return rbdg::grad_fpass_host<T, true>(m, q, qd, v, a, g, B, dv, da, df, st);                                                                 \
+  }                                                                                                                                              \
+  int rbd_g_rnea_grad_fpass_dqd_##SFX(const rbd_model* m, const T* q, const T* qd, const T* v, int64_t B, T* dv, T* da, T* df, void* st) {        \
+    return rbdg::grad_fpass_host<T, false>(m, q, qd, v, nullptr, T(0), B, dv, da, df, st);                                                       \
+  }                                                                                                                                              \
+  int rbd_g_rnea_grad_bpass_dq_##SFX(const rbd_model* m, const T* q, const T* f, T* df, int64_t B, T* dc, void* st) {                             \
+    return rbdg::grad_bpass_host<T, true>(m, q, f, df, 0, B, dc, st);                                                                            \
+  }                                                                                                                                              \
+  int rbd_g_rnea_grad_bpass_dqd_##SFX(const rbd_model* m, const T* q, T* df, int damp, int64_t B, T* dc, void* st) {                              \
+    return rbdg::grad_bpass_host<T, false>(m, q, nullptr, df, damp, B, dc, st);                                                                  \
+  }                                                                                                                                              \
+  int rbd_g_minv_bpass_##SFX(const rbd_model* m, const T* q, int64_t B, T* Mi, T* F, T* U, T* D, void* st) { return rbdg::minv_bpass_host<T>(m, q, B, Mi, F, U, D, st); } \
+  int rbd_g_minv_fpass_##SFX(const rbd_model* m, const T* q, int64_t B, T* Mi, T* F, const T* U, const T* D, void* st) {                          \
+    return rbdg::minv_fpass_host<T>(m, q, B, Mi, F, U, D, st);                                                                                   \
+  }                                                                                                                                              \
+  int rbd_g_crba_##SFX(const rbd_model* m, const T* q, int64_t B, T* H, void* st) { return rbdg::crba_host<T>(m, q, B, H, st); }
+RBDG_PASS_API(f32, float)
+RBDG_PASS_API(f64, double)
 
 }  // extern "C"

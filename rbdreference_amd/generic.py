@@ -28,7 +28,11 @@ GENERIC_EXPORTED_SYMBOLS = [
     "rbd_g_minv_f32", "rbd_g_minv_f64", "rbd_g_fd_workspace_bytes",
     "rbd_g_forward_dynamics_f32", "rbd_g_forward_dynamics_f64",
     "rbd_g_forward_dynamics_grad_f32", "rbd_g_forward_dynamics_grad_f64",
-]
+] + [f"rbd_g_{nm}_{sfx}" for sfx in ("f32", "f64") for nm in (
+    "rnea_fpass", "rnea_bpass", "rnea_grad_fpass_dq", "rnea_grad_fpass_dqd", "rnea_grad_bpass_dq", "rnea_grad_bpass_dqd",
+    "minv_bpass", "minv_fpass", "crba")]
+_PASS_NAMES = ("rnea_fpass", "rnea_bpass", "rnea_grad_fpass_dq", "rnea_grad_fpass_dqd", "rnea_grad_bpass_dq", "rnea_grad_bpass_dqd",
+               "minv_bpass", "minv_fpass", "crba")
 
 
 class RbdModelDesc(Structure):
@@ -76,6 +80,19 @@ def _declare(lib):
         f = getattr(lib, f"rbd_g_forward_dynamics_grad_{sfx}")
         f.restype = c_int
         f.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, ft, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        # per-pass surface + crba: the argument lists of include/rbd_hip.h behind the model handle
+        for nm, at in (("rnea_fpass", [c_void_p] * 3 + [ft, c_int64] + [c_void_p] * 4),
+                       ("rnea_bpass", [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+                       ("rnea_grad_fpass_dq", [c_void_p] * 4 + [ft, c_int64] + [c_void_p] * 4),
+                       ("rnea_grad_fpass_dqd", [c_void_p] * 3 + [c_int64] + [c_void_p] * 4),
+                       ("rnea_grad_bpass_dq", [c_void_p] * 3 + [c_int64] + [c_void_p] * 2),
+                       ("rnea_grad_bpass_dqd", [c_void_p] * 2 + [c_int, c_int64] + [c_void_p] * 2),
+                       ("minv_bpass", [c_void_p, c_int64] + [c_void_p] * 5),
+                       ("minv_fpass", [c_void_p, c_int64] + [c_void_p] * 5),
+                       ("crba", [c_void_p, c_int64, c_void_p, c_void_p])):
+            f = getattr(lib, f"rbd_g_{nm}_{sfx}")
+            f.restype = c_int
+            f.argtypes = [c_void_p] + at
 
 
 _LIB = None
@@ -146,6 +163,8 @@ class GenericModel:
         self._lock = threading.Lock()
         for sfx in ("f32", "f64"):
             for base in ("rnea", "rnea_grad", "forward_dynamics", "forward_dynamics_grad"):
+                setattr(self, f"rbd_{base}_{sfx}", self._bind(f"rbd_g_{base}_{sfx}"))
+            for base in _PASS_NAMES:                 # fixed base only (the library refuses a floating-base model)
                 setattr(self, f"rbd_{base}_{sfx}", self._bind(f"rbd_g_{base}_{sfx}"))
             setattr(self, f"rbd_minv_{sfx}", self._bind_minv(sfx))
             setattr(self, f"rbd_rnea_with_grad_{sfx}", self._bind_with_grad(sfx))
@@ -233,6 +252,8 @@ class GenericModel:
     def serves(self, base: str) -> bool:
         if base == "rbd_aba":
             return not self.model.floating       # (the reference's own aba raises for a floating base, :900)
+        if base.startswith("rbd_") and base[4:] in _PASS_NAMES:
+            return not self.model.floating       # per-pass surface + crba: fixed-base models
         return base in self.SERVES
 
     def kernel_name(self, op: int, elem_size: int) -> str:

@@ -342,3 +342,73 @@ def test_the_ctypes_stub_of_integration_md_runs_as_written():
     dc = torch.empty((B, n, 2 * n), dtype=torch.float64, device="cuda:0")
     assert h.L.rbd_g_rnea_grad_f64(h.h, tq.data_ptr(), tqd.data_ptr(), tqdd.data_ptr(), -9.81, 0, B, None, dc.data_ptr(), None) == 0
     check("dc_du through the documented stub", dc, orc.rnea_grad(orc.model_from_robot(robot), q, qd, qdd), TOL64)
+
+
+# ---- round 4: the per-pass surface (README.md:19 of the reference) and crba without a compiler --------------------------------
+@pytest.mark.parametrize("name", all_golden_names())
+def test_generic_per_pass_surface_and_crba_vs_golden(name, prec):
+    """rbd_g_rnea_fpass / bpass, rbd_g_rnea_grad_fpass_dq / dqd, rbd_g_rnea_grad_bpass_dq / dqd, rbd_g_minv_bpass / fpass and
+    rbd_g_crba (include/rbd_generic.h) against the reference's own per-pass outputs -- layouts, in-place mutation of f / df /
+    Minv and the by-products below Minv's diagonal included (RBDReference.py:559-621, :1127-1343, :630-783, :1091-1124) --
+    through RBDReference(robot, generic="only"): no per-robot library, no compiler."""
+    dt, tol = prec
+    torch = _torch()
+    g = load_golden(name); gen = generic_for(name); n = gen.n
+    q, qd, qdd = dev_tensors(dt, g["q"], g["qd"], g["qdd"])
+    # rnea passes
+    v, a, f = gen.rnea_fpass(q, qd, qdd)
+    assert gen._lib.served_by_generic()
+    check("fpass v", v, g["fpass_v"], tol); check("fpass a", a, g["fpass_a"], tol); check("fpass f (local)", f, g["fpass_f"], tol)
+    (f_in,) = dev_tensors(dt, g["fpass_f"])
+    c, f_ret = gen.rnea_bpass(q, f_in)
+    assert f_ret is f_in
+    check("bpass c", c, g["c"], tol); check("bpass f (accumulated, in place)", f_in, g["f_acc"], tol)
+    # gradient passes, fed as RBDReference.rnea_grad feeds them (:1353-1365)
+    v2, a2, f2 = dev_tensors(dt, g["fpass_v"], g["fpass_a"], g["f_acc"])
+    dv, da, df = gen.rnea_grad_fpass_dq(q, qd, v2, a2)
+    check("dv_dq", dv, g["dq_dv"], tol); check("da_dq", da, g["dq_da"], tol); check("df_dq", df, g["dq_df"], tol)
+    dv2, da2, df2 = gen.rnea_grad_fpass_dqd(q, qd, v2)
+    check("dv_dqd", dv2, g["dqd_dv"], tol); check("da_dqd", da2, g["dqd_da"], tol); check("df_dqd", df2, g["dqd_df"], tol)
+    gdf, gdf2 = dev_tensors(dt, g["dq_df"], g["dqd_df"])
+    check("dc_dq", gen.rnea_grad_bpass_dq(q, f2, gdf), g["dc_dq"], tol)
+    check("dc_dqd", gen.rnea_grad_bpass_dqd(q, gdf2.clone()), g["dc_dqd"], tol)
+    check("dc_dqd damped", gen.rnea_grad_bpass_dqd(q, gdf2.clone(), USE_VELOCITY_DAMPING=True), g["dc_dqd_damped"], tol)
+    check("dc_dq (chained)", gen.rnea_grad_bpass_dq(q, f2, df), g["dc_du"][:, :, :n], tol)
+    check("dc_dqd (chained)", gen.rnea_grad_bpass_dqd(q, df2), g["dc_du"][:, :, n:], tol)
+    # minv passes
+    Mb, F, U, D = gen.minv_bpass(q)
+    check("minv_bpass Minv", Mb, g["mb_Minv"], tol); check("minv_bpass F", F, g["mb_F"], tol)
+    check("minv_bpass U", U, g["mb_U"], tol); check("minv_bpass Dinv (= D)", D, g["mb_Dinv"], tol)
+    M = gen.minv_fpass(q, Mb, F, U, D)
+    assert M is Mb
+    check("minv_fpass Minv (whole matrix, junk included)", M, g["Minv_upper"], tol)
+    gM, gF, gU, gD = dev_tensors(dt, g["mb_Minv"], g["mb_F"], g["mb_U"], g["mb_Dinv"])
+    check("minv_fpass on golden inputs", gen.minv_fpass(q, gM, gF, gU, gD), g["Minv_upper"], tol)
+    # crba
+    H = gen.crba(q)
+    check("H", H, g["H"], tol)
+    assert torch.equal(H, H.transpose(1, 2))
+
+
+def test_generic_per_pass_surface_ragged_and_refusals():
+    """A ragged batch against the oracle, and the floating-base refusal (the reference's own crba raises there, :1063)."""
+    torch = _torch()
+    from oracle import rbd_oracle as orc
+    from rbdreference_amd._lib import RbdError
+    gen = generic_for("random_tree_n9"); om = orc.model_from_robot(make_robot("random_tree_n9")); n = gen.n
+    rng = np.random.default_rng(12)
+    B = 131
+    q, qd, qdd = (rng.uniform(-3, 3, (B, n)), rng.uniform(-1, 1, (B, n)), rng.uniform(-1, 1, (B, n)))
+    tq, tqd, tqdd = dev_tensors(torch.float64, q, qd, qdd)
+    _, v, a, f = orc.rnea(om, q, qd, qdd)
+    dvr, dar, dfr = orc.rnea_grad_fpass_dq(om, q, qd, v, a)
+    tv, ta = dev_tensors(torch.float64, v, a)
+    dv, da, df = gen.rnea_grad_fpass_dq(tq, tqd, tv, ta)
+    check("ragged df_dq", df, dfr, TOL64); check("ragged dv_dq", dv, dvr, TOL64)
+    check("ragged H", gen.crba(tq), orc.crba(om, q), TOL64)
+    Mb, F, U, D = gen.minv_bpass(tq)
+    Mr, Fr, Ur, Dr = orc.minv_bpass(om, q)
+    check("ragged minv_bpass F", F, Fr, TOL64); check("ragged minv_bpass Minv", Mb, Mr, TOL64)
+    fbg = generic_for("fb_random_tree_n6")
+    with pytest.raises(RbdError):
+        fbg.crba(torch.zeros((3, fbg.nv), device="cuda:0", dtype=torch.float64))

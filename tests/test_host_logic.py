@@ -355,8 +355,11 @@ def test_generic_library_loads_exports_its_header_and_serves_a_never_built_robot
     assert f is not None and (L.served_by_generic() or L._full is not None)
     assert L.kernel_name(1, 4, 1 << 20).startswith(("g_rnea_grad_kernel<float, 8>", "rnea_grad_"))
     assert isinstance(L._generic, GenericModel) and not L._fams
-    L.fn("rbd_crba", "f32")                               # not served by the model-handle library
-    assert ("minv", "f32") in L._fams or L._full is not None
+    L.fn("rbd_crba", "f32")                               # round 4: the per-pass surface and crba are served too (fixed base)
+    assert L.served_by_generic() or L._full is not None
+    for base in ("rbd_rnea_fpass", "rbd_rnea_bpass", "rbd_rnea_grad_fpass_dq", "rbd_rnea_grad_fpass_dqd", "rbd_rnea_grad_bpass_dq",
+                 "rbd_rnea_grad_bpass_dqd", "rbd_minv_bpass", "rbd_minv_fpass"):
+        assert L._generic.serves(base) and callable(getattr(L._generic, base + "_f64"))
     L.wait_specialized()
     L.fn("rbd_rnea_grad", "f32")
     assert not L.served_by_generic()
@@ -365,8 +368,13 @@ def test_generic_library_loads_exports_its_header_and_serves_a_never_built_robot
     assert only.served_by_generic() and only.get_option(0) == 0
     only.fn("rbd_aba", "f32")                              # Minv (tau - c) through rbd_g_forward_dynamics
     assert only.served_by_generic()
-    with pytest.raises(Exception, match="not served by the model-handle library"):
-        only.fn("rbd_crba", "f32")
+    only.fn("rbd_crba", "f32")
+    assert only.served_by_generic()
+    # a FLOATING-base robot: the model-handle library serves its five products, not the per-pass surface / crba
+    from rbdreference_amd.robot import FloatingBaseRobot, random_tree
+    fbm = pack_robot(FloatingBaseRobot(random_tree([-1, 0, 1, 0, 3, 3], seed=5, name="t6"), "generic_probe_fb6"))
+    gfb = GenericModel(fbm, build=True)
+    assert gfb.serves("rbd_rnea_grad") and not gfb.serves("rbd_crba") and not gfb.serves("rbd_minv_bpass")
 
 
 def test_a_machine_without_hipcc_keeps_serving_from_the_model_handle_library(monkeypatch):
@@ -385,5 +393,7 @@ def test_a_machine_without_hipcc_keeps_serving_from_the_model_handle_library(mon
     assert L.wait_specialized() is L and L._bg_err is not None
     L.fn("rbd_minv", "f64")
     assert L.served_by_generic()
-    with pytest.raises(RuntimeError, match="hipcc not found"):
-        L.fn("rbd_crba", "f32")
+    L.fn("rbd_crba", "f32")                            # (round 4: served without a compiler too)
+    assert L.served_by_generic()
+    L.fn("rbd_minv_bpass", "f64")
+    assert L.served_by_generic()
