@@ -51,6 +51,9 @@ def parse():
                     help="rows per step: the global batch (strong scaling) / rows per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--rotate", type=int, default=4, help="input/output buffer sets cycled through by the steps")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="time the K steps as ONE replay of a HIP graph of K launches (auto: strong scaling on more than one GPU, "
+                         "where a rank's shard is small enough for the launch path to show)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
@@ -94,6 +97,38 @@ class GradStep:
         rc = self.fn(*a)
         if rc != 0:
             self.rbd._lib.check(rc)
+
+    def on_stream(self, st):
+        """The next launch on stream `st` (a raw hipStream_t) instead of the stream this object was built on."""
+        a = self.args[self.k]
+        self.k = (self.k + 1) % len(self.args)
+        rc = self.fn(*a[:-1], st)
+        if rc != 0:
+            self.rbd._lib.check(rc)
+
+
+class GraphSteps:
+    """K launches of a `GradStep` captured ONCE into a HIP graph; calling the object replays all K.  For shards so small that
+    the gap between eager launches is a fifth of the step (131 072 rows per rank at N = 8, 20.6 us per
+    eager launch around an 18 us kernel) the graph takes the launch path out of the step; the work is the same K launches
+    on the same rotating buffer sets."""
+
+    def __init__(self, step, K, dev):
+        self.K = K
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step.on_stream(side.cuda_stream)            # everything the launch path sets up lazily happens outside the capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            for _ in range(K):
+                step.on_stream(st)
+
+    def __call__(self):
+        self.graph.replay()
 
 
 def time_kernel_ms(fn, steps, warmup):
@@ -182,11 +217,18 @@ def sources_digest():
     return h.hexdigest()[:16]
 
 
-def timed_steps(step, steps, warmup, dist, dev):
+def timed_steps(step, steps, warmup, dist, dev, graph=False):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.
-    Returns (wall seconds, HIP-event ms per step on the launch stream): this rank's."""
+    Returns (wall seconds, HIP-event ms per step on the launch stream): this rank's.
+    graph: the K steps are captured (untimed) into one HIP graph and the timed region is its replay -- the same K launches."""
+    run = None
+    if graph:
+        gs = GraphSteps(step, steps, dev)
+        run = gs
     for _ in range(warmup):
         step()
+    if run is not None:
+        run()                                    # one untimed replay (graph upload)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -194,8 +236,11 @@ def timed_steps(step, steps, warmup, dist, dev):
     ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(steps):
-        step()
+    if run is not None:
+        run()
+    else:
+        for _ in range(steps):
+            step()
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0          # this rank's K steps, device-synchronised; MAX over ranks below
@@ -267,14 +312,15 @@ def main():
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-    wall, kern_ms = timed_steps(step, args.steps, args.warmup, dist, dev)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1 and args.scaling == "strong")
+    wall, kern_ms = timed_steps(step, args.steps, args.warmup, dist, dev, graph=use_graph)
 
     other = None
     if world > 1:                            # the other scaling mode, same run, reported beside the headline
         omode = "weak" if args.scaling == "strong" else "strong"
         ostep = make_step(omode)
         rbd._lib.set_option(RBD_OPT_SELECT_BATCH, B if omode == "strong" else 0)
-        ow, ok = timed_steps(ostep, args.steps, args.warmup, dist, dev)
+        ow, ok = timed_steps(ostep, args.steps, args.warmup, dist, dev, graph=(args.graph == "on" or (args.graph == "auto" and omode == "strong")))
         rbd._lib.set_option(RBD_OPT_SELECT_BATCH, 0)
         orows = B if omode == "strong" else world * B
         other = {"scaling": omode, "value": orows * args.steps / ow, "unit": "evals/s", "ms_per_step": ow / args.steps * 1e3,
@@ -335,9 +381,12 @@ def main():
                                    f"{nsets} buffer sets rotated",
                        "robot": "iiwa_like", "batch_per_gpu": rows_rank, "global_batch": rows_global,
                        "buffer_sets": nsets,
+                       "launch": (f"one replay of a HIP graph of the {args.steps} launches" if use_graph else "eager launches"),
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
             "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac_from_ms_per_step": (rows_rank * BYTES_PER_EVAL / (wall / args.steps) / 1e9) / HBM_PEAK_GBS,
+                         "frac_uses": "kernel_ms (HIP events around the K launches on the launch stream); frac_from_ms_per_step divides by the wall-clock step instead",
                          "algorithmic_bytes_per_eval": BYTES_PER_EVAL, "kernel": kernel,
                          "kernel_ms": kern_ms, "sources_digest": digest, "valu": valu,
                          "valu_frac_of_peak": valu_frac, "valu_tflops": valu_tflops,
@@ -540,11 +589,19 @@ def main():
                     ss = GradStep(rbd, [(qs, qds, qdds)])
                     ms = time_extra_ms(ss, 50, 10)
                     kn = rbd._lib.kernel_name(RBD_OP_RNEA_GRAD, 4, Bs)
+                    NG = 50
+                    gs = GraphSteps(ss, NG, dev)
+                    msg = time_extra_ms(gs, 20, 3) / NG
                 extra["cfg3_per_rank_shard_B131072_of_1M_f32"] = {
                     "ms_per_launch": ms, "evals_per_s": Bs / (ms * 1e-3), "alg_GBps": Bs * BYTES_PER_EVAL / (ms * 1e-3) / 1e9,
                     "kernel": kn, "predicted_8gpu_strong_scaling_evals_per_s": (1 << 20) / (ms * 1e-3),
+                    "ms_per_launch_graph": msg, "alg_GBps_graph": Bs * BYTES_PER_EVAL / (msg * 1e-3) / 1e9,
+                    "predicted_8gpu_strong_scaling_evals_per_s_graph": (1 << 20) / (msg * 1e-3),
                     "note": "one rank's share of the 1 048 576-row global batch; 8 ranks run it concurrently with no "
-                            "data-path collective, so the N = 8 strong-scaling value is bounded by (1 M rows) / this time"}
+                            "data-path collective, so the N = 8 strong-scaling value is bounded by (1 M rows) / this time.  "
+                            "`_graph`: the same launches replayed from one HIP graph of 50 (what bench.py --gpus N > 1 times "
+                            "in strong mode: the launch path leaves the step)"}
+                del gs
                 del ss
             except Exception as e:
                 extra["cfg3_shard_error"] = repr(e)

@@ -14,7 +14,7 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
 done
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  REPS=6 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_cfg_$tag -- python3 tools/run_configs.py atlas atlas64 iiwa4k quad fb > $OUT/pmc_cfg_$tag.log 2>&1 || echo "pmc cfg $tag failed"
+  REPS=6 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_cfg_$tag -- python3 tools/run_configs.py atlas atlas64 iiwa4k quad fb fdg > $OUT/pmc_cfg_$tag.log 2>&1 || echo "pmc cfg $tag failed"
 done
 bash tools/pmc_stalls.sh ${1:-prof}/stalls > $OUT/pmc_stalls.log 2>&1 || echo "pmc stalls failed"
 mkdir -p $OUT/head $OUT/cfg

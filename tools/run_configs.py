@@ -31,4 +31,11 @@ if "iiwa" in which:
     q, qd, qdd = inputs(1 << 20, 7, 3, torch.float32)
     for _ in range(REPS): r.rnea(q, qd, qdd); r.minv(q); r.aba(q, qd, qdd)
     for _ in range(max(2, REPS // 4)): r.forward_dynamics_grad(q, qd, qdd)
+if "fdg" in which:        # forward_dynamics_grad of the three fixed-base BASELINE robots at their batch sizes
+    r = RBDReference(iiwa_like(), build=False); q, qd, qdd = inputs(1 << 20, 7, 3, torch.float32)
+    for _ in range(max(3, REPS // 2)): r.forward_dynamics_grad(q, qd, qdd)
+    r = RBDReference(atlas_like(), build=False); q, qd, qdd = inputs(16384, 30, 2, torch.float32)
+    for _ in range(max(3, REPS // 2)): r.forward_dynamics_grad(q, qd, qdd)
+    r = RBDReference(quadruped_like(), build=False); q, qd, qdd = inputs(65536, 12, 4, torch.float64)
+    for _ in range(max(3, REPS // 2)): r.forward_dynamics_grad(q, qd, qdd)
 torch.cuda.synchronize()
