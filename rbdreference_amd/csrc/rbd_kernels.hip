@@ -1937,12 +1937,16 @@ __global__ __launch_bounds__(64 * MINV_COLS_W, MINV_COLS_MIN_WAVES) void minv_co
 #endif
 namespace rbdk {
 #ifdef RBD_NO_MINV_LANE
-constexpr bool MINV_USE_LANE = false;
+template <class T>
+constexpr bool minv_use_lane() { return false; }
 #else
-constexpr bool MINV_USE_LANE = MINV_LANE_OK;
+template <class T>
+constexpr bool minv_use_lane() { return minv_lane_ok<T>(); }
 #endif
-// scalars of HBM workspace per configuration (none for the fused one-lane kernel)
-constexpr size_t MINV_WS_PER_CFG = MINV_USE_LANE ? 0 : (size_t)N * MINV_WS;
+// scalars of HBM workspace per configuration (none where the one-lane kernel serves BOTH precisions; a robot it serves in
+// fp32 only keeps the size the fp64 path needs -- rbd_minv_workspace_bytes does not know the caller's kernel -- and the fp32
+// launch ignores the buffer)
+constexpr size_t MINV_WS_PER_CFG = (minv_use_lane<float>() && minv_use_lane<double>()) ? 0 : (size_t)N * MINV_WS;
 }  // namespace rbdk
 
 // =============================================================================================
@@ -2539,7 +2543,7 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
   if (B == 0) return 0;
   if (!q || (!Minv && !qdd)) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
   if ((reinterpret_cast<uintptr_t>(Minv) & 15u) != 0) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be 16-byte aligned");
-  if constexpr (MINV_USE_LANE) {
+  if constexpr (minv_use_lane<T>()) {
     // fused one-lane-per-configuration kernel (rbd_minv_lane.h): no workspace
     const int64_t blocks = (B + 63) / 64;
     if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
@@ -2609,11 +2613,11 @@ int minv_kernel_name(int64_t B, char* buf, size_t len) {
   const char* t = sizeof(T) == 4 ? "float" : "double";
   const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
   bool fused = false;
-  if constexpr (!rbdk::MINV_USE_LANE) {
+  if constexpr (!rbdk::minv_use_lane<T>()) {
     if constexpr (rbdk::MINV_FUSED_OK && rbdk::mf_lds_bytes<T>() <= 160 * 1024)
       fused = pa == RBD_MINV_PHASE_A_FUSED || pa == RBD_MINV_PHASE_A_AUTO;
   }
-  if (rbdk::MINV_USE_LANE) std::snprintf(buf, len, "minv_lane_kernel<%s>", t);
+  if (rbdk::minv_use_lane<T>()) std::snprintf(buf, len, "minv_lane_kernel<%s>", t);
   else if (fused) std::snprintf(buf, len, "minv_fused_kernel<%s>", t);
   else std::snprintf(buf, len, "minv_cols_kernel<%s>", t);
   return 0;
@@ -2622,7 +2626,7 @@ int minv_kernel_name(int64_t B, char* buf, size_t len) {
 // does minv_launch<T> go through the HBM workspace under the current options?
 template <class T>
 int minv_needs_workspace() {
-  if constexpr (rbdk::MINV_USE_LANE) return 0;
+  if constexpr (rbdk::minv_use_lane<T>()) return 0;
   if constexpr (rbdk::MINV_FUSED_OK && rbdk::mf_lds_bytes<T>() <= 160 * 1024) {
     const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
     if (pa == RBD_MINV_PHASE_A_FUSED || pa == RBD_MINV_PHASE_A_AUTO) return 0;

@@ -16,12 +16,25 @@
 
 namespace rbdk {
 
-constexpr bool MINV_LANE_OK = GRAD_PER_ROOT && grad_max_rows() <= 8;
+// (round 4: also robots whose root subtrees INTERLEAVE in the numbering -- GRAD_PER_ROOT false, the whole robot is one group --
+// when that group has at most 8 bodies: columns of the other root's bodies are structural zeros the sweeps pass through, and
+// the two-phase path such a robot used to take ran at 7.5 % of HBM peak, 596 GB/s for the 8-body forest at B = 65 536)
+constexpr bool MINV_LANE_OK = grad_max_rows() <= 8;
+// (round 4, "topology lottery": for mid-size trees -- a 14-body torso with three limbs, two 9-body chains, dense frames -- the
+// two-phase / eight-lane paths run at 0.12-0.19 of HBM peak.  With the articulated inertias kept as 21-scalar symmetric
+// matrices a lone wave's registers do hold such a group in fp32 (223 / 167 VGPRs, no scratch: -DMINV_LANE_MAX_F32=14), but
+// the unrolled kernel is 15-17 k instructions = 120-140 KB of code that lone waves stream through a 64 KB instruction
+// cache: 52 / 77 us at B = 65 536 against 46-49 / 68 us for the one-lane phase A + column kernel.  The limit stays at 8.)
+#ifndef MINV_LANE_MAX_F32
+#define MINV_LANE_MAX_F32 8
+#endif
+template <class T>
+constexpr bool minv_lane_ok() { return grad_max_rows() <= (sizeof(T) == 4 ? MINV_LANE_MAX_F32 : 8); }
 // LDS stride between configurations (odd => conflict-free per-lane rows)
 constexpr int MINV_LANE_TS = (grad_max_rows() * N) | 1;
 
 template <class T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void minv_lane_kernel(const T* __restrict__ q, long long B, int dense,
+__global__ __launch_bounds__(64, (sizeof(T) == 4 && grad_max_rows() <= 8) ? 2 : 1) void minv_lane_kernel(const T* __restrict__ q, long long B, int dense,
                                                                               T* __restrict__ Minv, const T* __restrict__ u_in,
                                                                               const T* __restrict__ c_in, T* __restrict__ qdd_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -51,14 +64,16 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void minv_lane_kernel(c
     constexpr int row0 = grp_row0(rt);
     constexpr int rows = grp_rows(rt);
     T* my = tile + lane * MINV_LANE_TS - row0 * N;     // my[i * N + c], rows of this group
-    // ---- articulated inertias of the group (:662, :697-700, :728-733) ---------------------------
+    // ---- articulated inertias of the group (:662, :697-700, :728-733); IA is symmetric: 21 scalars per body, the lower half
+    //      of X^T Ia X is never formed ------------------------------------------------------------------------------------
     {
-      T IA[N][6][6];
+      constexpr auto sy = [](int r, int c) constexpr { return r <= c ? r * 6 - r * (r - 1) / 2 + (c - r) : c * 6 - c * (c - 1) / 2 + (r - c); };
+      T IA[N][21];
       sfor<row0, row0 + rows>([&](auto J) {
         sfor<0, 6>([&](auto R) {
           sfor<0, 6>([&](auto C) {
             constexpr int j = decltype(J)::value, r = decltype(R)::value, c = decltype(C)::value;
-            IA[j][r][c] = T(IM[j][r * 6 + c]);
+            if constexpr (r <= c) IA[j][sy(r, c)] = T(IM[j][r * 6 + c]);
           });
         });
       });
@@ -66,23 +81,23 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1) void minv_lane_kernel(c
         constexpr int i = decltype(I)::value;
         constexpr int p = PARENT[i];
         constexpr int si = s_index(i);
-        sfor<0, 6>([&](auto R) { U[i][decltype(R)::value] = IA[i][decltype(R)::value][si]; });   // U = IA S
-        Dinv[i] = T(1) / U[i][si];                                                                // 1 / (S^T U)
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[i][r] = IA[i][sy(r, si)]; });   // U = IA S
+        Dinv[i] = T(1) / U[i][si];                                                                        // 1 / (S^T U)
         if constexpr (p >= 0) {
           T A[6][6];   // A = X^T Ia, Ia = IA - U U^T / D
           sfor<0, 6>([&](auto C) {
             constexpr int c = decltype(C)::value;
             T col[6], y[6];
             const T uc = U[i][c] * Dinv[i];
-            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[i][r], uc, IA[i][r][c]); });
+            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[i][r], uc, IA[i][sy(r, c)]); });
             xform_T<i>(tr[i], col, y);
             sfor<0, 6>([&](auto R) { A[decltype(R)::value][c] = y[decltype(R)::value]; });
           });
-          sfor<0, 6>([&](auto R) {   // IA_p += (A X): row r of A X = X^T A[r][:]^T
+          sfor<0, 6>([&](auto R) {   // IA_p += (A X), upper triangle: row r of A X = X^T A[r][:]^T
             constexpr int r = decltype(R)::value;
             T y[6];
             xform_T<i>(tr[i], A[r], y);
-            sfor<0, 6>([&](auto C) { IA[p][r][decltype(C)::value] += y[decltype(C)::value]; });
+            sfor<r, 6>([&](auto C) { constexpr int c = decltype(C)::value; IA[p][sy(r, c)] += y[c]; });
           });
         }
       });
