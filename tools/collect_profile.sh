@@ -10,7 +10,7 @@ cp $O/pmc_cfg_summary.json profiles/${T}_pmc_configs.json
 cp $O/bench.json profiles/${T}_bench.json.log
 cp $O/stalls/pmc_stalls.txt profiles/${T}_pmc_stalls.txt
 cp $O/bench_torchrun1.json profiles/${T}_bench_torchrun1.json.log
-python tools/make_traffic.py $O/pmc_head_summary.json rnea_grad_idsva 1048576 > /dev/null
+python tools/make_traffic.py $O/pmc_head_summary.json "rnea_grad_idsva_pipe_kernel<float,true,false>" 1048576 > /dev/null
 python tools/make_config_traffic.py profiles/${T}_pmc_configs.json > /dev/null
 python - <<P
 import bench, json

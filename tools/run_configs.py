@@ -8,7 +8,7 @@ REPS = int(os.environ.get("REPS", "20"))
 def inputs(B, n, seed, dt):
     rng = np.random.default_rng(seed)
     return [torch.tensor(x, dtype=dt, device="cuda") for x in (rng.uniform(-np.pi, np.pi, (B, n)), rng.uniform(-1, 1, (B, n)), rng.uniform(-1, 1, (B, n)))]
-which = sys.argv[1:] or ["atlas", "quad", "iiwa", "fb"]
+which = sys.argv[1:] or ["atlas", "quad", "iiwa", "fb", "fdg"]
 if "atlas" in which:
     r = RBDReference(atlas_like(), build=False); q, qd, qdd = inputs(16384, 30, 2, torch.float32)
     for _ in range(REPS): r.minv(q); r.rnea(q, qd, qdd); r.rnea_grad(q, qd, qdd, return_c=True); r.aba(q, qd, qdd)
