@@ -410,6 +410,44 @@ def test_forward_dynamics_vs_golden(name, prec):
     check("fd_dqd", b.contiguous(), g["fd_dqd"], tol_fd)
 
 
+@pytest.mark.parametrize("name,B", [("iiwa_like", (1 << 20) + 37), ("random_chain_n7", 65536 + 5), ("quadruped_like", 65536), ("atlas_like", 16384)])
+@pytest.mark.parametrize("precision", ["float32", "float64"])
+def test_forward_dynamics_grad_full_size(name, B, precision):
+    """forward_dynamics_grad at BASELINE sizes (plus a ragged tail for the chains: the two-launch path of rbd_fd_chain.h keeps
+    Minv in whole 64-row tiles), both precisions.  Size-independent property: it IS -minv(q) rnea_grad(q, qd, qdd) with
+    qdd = forward_dynamics(q, qd, u) (RBDReference.py:1376-1384) -- recomputed from the three separate entry points on
+    the device for EVERY row -- and sampled rows (tile boundaries, the last rows) equal the oracle."""
+    from oracle import rbd_oracle as orc
+    torch = _torch()
+    rbd = rbd_for(name); om = orc.model_from_robot(make_robot(name)); n = rbd.n
+    f32 = precision == "float32"
+    dt = torch.float32 if f32 else torch.float64
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(B)
+    q = (torch.rand((B, n), device="cuda:0", generator=gen, dtype=dt) * 2 - 1) * np.pi
+    qd = torch.rand((B, n), device="cuda:0", generator=gen, dtype=dt) * 2 - 1
+    u = (torch.rand((B, n), device="cuda:0", generator=gen, dtype=dt) * 2 - 1) * 5
+    a, b = rbd.forward_dynamics_grad(q, qd, u)
+    assert a.shape == (B, n, n) and b.shape == (B, n, n) and torch.isfinite(a).all() and torch.isfinite(b).all()
+    qdd = rbd.forward_dynamics(q, qd, u)
+    dc = rbd.rnea_grad(q, qd, qdd)
+    Mi = rbd.minv(q)
+    want = -torch.einsum("bij,bjk->bik", Mi.double(), dc.double())
+    got = torch.cat([a, b], dim=2).double()
+    err = ((got - want).abs().amax(dim=(1, 2)) / want.abs().amax(dim=(1, 2)).clamp_min(1e-30)).max().item()
+    # fp32: qdd of the two routes differs by rounding amplified by cond(H) (<= ~1e4 here), and dc_dq is affine in qdd
+    assert err < (2e-2 if f32 else 1e-8), err
+    idx = np.unique(np.concatenate([[0, 1, 63, 64, 65, B - 65, B - 64, B - 2, B - 1], np.random.default_rng(1).integers(0, B, 120)]))
+    tidx = torch.tensor(idx, device="cuda:0")
+    qs, qds, us = (x[tidx].double().cpu().numpy() for x in (q, qd, u))
+    r1, r2 = orc.forward_dynamics_grad(om, qs, qds, us)
+    if f32:
+        H = orc.crba(om, qs)
+        check_conditioned("fd_dq sample", a[tidx].contiguous(), r1, H, slack=2 * COND_SLACK)
+        check_conditioned("fd_dqd sample", b[tidx].contiguous(), r2, H, slack=2 * COND_SLACK)
+    else:
+        check("fd_dq sample", a[tidx].contiguous(), r1, 1e-8); check("fd_dqd sample", b[tidx].contiguous(), r2, 1e-8)
+
+
 def test_forward_dynamics_round_trip_full_size():
     """rnea(q, qd, forward_dynamics(q, qd, u)) == u at B = 1M (fp32), ragged B, numpy path."""
     torch = _torch()
