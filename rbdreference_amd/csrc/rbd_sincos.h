@@ -2,7 +2,7 @@
 // without any libm / ocml routine (the reference evaluates Xmat(q) = f(sin q, cos q) for any q in fp64,
 // /root/reference/RBDReference.py:562-564, :574).
 //
-// Why there is no library call in here (round 3 fault, round 4 root cause; DESIGN.md section 3.1 a' (xv)):
+// Why there is no library call in here (round 3 fault, round 4 root cause; docs/NOTEBOOK.md 3.1 a' (xv)):
 // `sincos(double)` / `sincosf(float)` of the device library carry a lane-masked `if (|x| large) {Payne-Hanek} else {..}`.
 // In register-starved fp64 kernels (AGPRs in use) the register allocator put a live-range copy of a CALLER value
 // (`v_accvgpr_write_b32 a1, v73`, the high half of a 64-bit address offset) at the head of that ELSE block, BEFORE the

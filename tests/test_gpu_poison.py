@@ -1,6 +1,6 @@
 """GPU tests of the sin / cos paths no ordinary input reaches (run with ``-m gpu``): huge angles, NaN and +-Inf in q.
 
-Why this file exists (DESIGN.md section 3.1 a' (xv)): round 3 hit an aperture fault in
+Why this file exists (docs/NOTEBOOK.md 3.1 a' (xv)): round 3 hit an aperture fault in
 `rnea_grad_idsva_kernel<double>` whose cause sat inside the device library's `sincos(double)` -- a lane-masked
 if / else in whose EXEC = 0 window the register allocator had placed a copy of a caller value.  Round 3 routed
 |q| <= 1e6 around the library; round 4 removed the library routines from the device code altogether

@@ -184,7 +184,7 @@ def test_kernels_of_built_libraries_do_not_spill():
 
 
 def test_no_vector_write_sits_in_an_exec_masked_window_and_no_kernel_calls_out():
-    """The round-3 aperture fault (DESIGN.md section 3.1 a' (xv)) was a register copy the compiler had placed at the head of
+    """The round-3 aperture fault (docs/NOTEBOOK.md 3.1 a' (xv)) was a register copy the compiler had placed at the head of
     the ELSE block of the device library's lane-masked `if (|x| large)`, before EXEC is restored there.  Round 4 removed
     the library sin / cos (csrc/rbd_sincos.h is straight-line code); this guards the ISA of whatever libraries are built:
     no vector instruction between a label `s_cbranch_execz` jumps to and the first rewrite of EXEC, no out-of-line

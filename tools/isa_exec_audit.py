@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Audit the gfx950 ISA of a per-robot library for vector writes that execute in an EXEC-masked window.
 
-Background (DESIGN.md section 3.1 a' (xv), round 3): `rnea_grad_idsva_kernel<double>` faulted because the register
+Background (docs/NOTEBOOK.md 3.1 a' (xv), round 3): `rnea_grad_idsva_kernel<double>` faulted because the register
 allocator had placed a live-range copy (`v_accvgpr_write_b32 a1, v73`) at the HEAD of the ELSE side of a lane-masked
 if / else -- i.e. in the block that `s_cbranch_execz` of the IF side jumps to -- BEFORE the instruction that restores
 EXEC there (`s_or_saveexec_b64` / `s_andn2_saveexec_b64`).  When no lane takes the IF side the branch arrives with
