@@ -130,19 +130,18 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? RBD_FDP_MINW : 1) void fd_pre_
     });
   }
 
-  // ---- one column of Minv at a time (:700-726, :760-781); qdd = Minv tau on the way --------------------------------
-  T qacc[N];
-  sfor<0, N>([&](auto J) { qacc[decltype(J)::value] = T(0); });
-  T* mp = minv_pk + (size_t)blockIdx.x * (FDC_NP * 64) + lane;
-#ifdef RBD_FDP_EXP_NOCOLS
-  sfor<0, N>([&](auto JC) { constexpr int jc = decltype(JC)::value; mp[fdc_slot(jc, jc) * 64] = Dinv[jc] + U[jc][0] + tau[jc]; });
-  sfor<0, 0>([&](auto JC) {
-#else
+  // ---- Minv.  Backward sweeps only (:700-726): column jc climbs its root path and leaves m[k][jc] = Minv_bpass[k, jc] for every
+  //      ancestor-or-self k.  The reference's forward pass (:760-781, n (n + 1) / 2 more six-vector transforms) is replaced by
+  //      the factorisation it evaluates (the articulated-body "innovations" form, exact -- checked at 2e-16 against the
+  //      reference's Minv on every golden robot, tools/check_minv_factorisation.py):
+  //          Minv[i, j] = sum over k in anc(i) & anc(j) of  D_k m[k][i] m[k][j],      m[k][k] = 1 / D_k
+  //      i.e. ~n^3 / 6 scalar FMAs.  qdd = Minv tau from the symmetric result. ------------------------------------------------
+  T Mb[N][N];
   sfor<0, N>([&](auto JC) {
-#endif
     constexpr int jc = decltype(JC)::value;
-    T mcol[N];
-    sfor<0, jc + 1>([&](auto I) { mcol[decltype(I)::value] = T(0); });
+#ifdef RBD_FDP_EXP_NOCOLS
+    Mb[jc][jc] = Dinv[jc] + U[jc][0] + tau[jc];
+#else
     T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     sfor_down<0, jc + 1>([&](auto I) {
       constexpr int i = decltype(I)::value;
@@ -151,8 +150,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? RBD_FDP_MINW : 1) void fd_pre_
         T m;
         if constexpr (i == jc) m = Dinv[i];
         else m = -(Dinv[i] * S_dot<i>(Fj));
-        mcol[i] = m;
-        if constexpr (p >= 0) {
+        Mb[i][jc] = m;
+        if constexpr (p >= 0 && i > 0) {
           T t[6], y[6];
           sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = (i == jc) ? U[i][r] * m : fma_(U[i][r], m, Fj[r]); });
           xform_T<i>(tr[i], t, y);
@@ -160,29 +159,39 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? RBD_FDP_MINW : 1) void fd_pre_
         }
       }
     });
-    T Ff[N][6];
-    sfor<0, jc + 1>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int p = PARENT[i];
-      constexpr int si = s_index(i);
-      if constexpr (p < 0) {
-        sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
-        Ff[i][si] = mcol[i];
-      } else {
-        xform<i>(tr[i], Ff[p], Ff[i]);
-        const T m = fma_(-Dinv[i], dot6(U[i], Ff[i]), mcol[i]);
-        mcol[i] = m;
-        Ff[i][si] += m;
-      }
-    });
-    // column jc is final for rows i <= jc: the packed image (whole tiles: also the lanes past the batch) and Minv tau
-    sfor<0, jc + 1>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      mp[fdc_slot(i, jc) * 64] = mcol[i];
-      qacc[i] = fma_(mcol[i], tau[jc], qacc[i]);
-      if constexpr (i < jc) qacc[jc] = fma_(mcol[i], tau[i], qacc[jc]);
-    });
+#endif
   });
+  T qacc[N];
+  sfor<0, N>([&](auto J) { qacc[decltype(J)::value] = T(0); });
+  T* mp = minv_pk + (size_t)blockIdx.x * (FDC_NP * 64) + lane;
+#ifndef RBD_FDP_EXP_NOCOLS
+  {
+    T W[N][N];                                                    // W[k][i] = D_k m[k][i]  (k a proper ancestor of i)
+    sfor<0, N>([&](auto I) {
+      sfor<0, N>([&](auto K) {
+        constexpr int i = decltype(I)::value, k = decltype(K)::value;
+        if constexpr (k != i && is_anc_or_self(k, i)) W[k][i] = U[k][s_index(k)] * Mb[k][i];
+      });
+    });
+    sfor<0, N>([&](auto J) {
+      sfor<0, N>([&](auto I) {
+        constexpr int i = decltype(I)::value, j = decltype(J)::value;
+        if constexpr (i <= j && is_anc_or_self(i, j)) {           // (a chain: every i <= j is an ancestor-or-self of j)
+          T acc = Mb[i][j];                                       // k = i: D_i m[i][i] m[i][j] = m[i][j]
+          sfor<0, N>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k != i && is_anc_or_self(k, i)) acc = fma_(W[k][i], Mb[k][j], acc);
+          });
+          mp[fdc_slot(i, j) * 64] = acc;
+          qacc[i] = fma_(acc, tau[j], qacc[i]);
+          if constexpr (i < j) qacc[j] = fma_(acc, tau[i], qacc[j]);
+        }
+      });
+    });
+  }
+#else
+  sfor<0, N>([&](auto JC) { constexpr int jc = decltype(JC)::value; mp[fdc_slot(jc, jc) * 64] = Mb[jc][jc]; });
+#endif
   if (lane < nvalid) {
     sfor<0, N>([&](auto I) { constexpr int i = decltype(I)::value; qdd_out[b * N + i] = qacc[i]; });
   }

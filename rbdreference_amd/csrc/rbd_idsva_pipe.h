@@ -259,7 +259,11 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
         int lo = lane;
         asm volatile("" : "+v"(lo));
         const T* mp = minv_pk + (size_t)tcur * (FDC_NP * 64) + lo;
+#ifdef RBD_FDG_EXP_NOLOAD        // timing experiment (results are wrong): no Minv loads
+        sfor<0, FDC_NP>([&](auto S_) { constexpr int s_ = decltype(S_)::value; mk[s_] = launder(T(1) + T(s_)); });
+#else
         sfor<0, FDC_NP>([&](auto S_) { constexpr int s_ = decltype(S_)::value; mk[s_] = mp[s_ * 64]; });
+#endif
         IDS_SB();
       }
       // world rigid inertia of body j about the world origin
@@ -631,7 +635,12 @@ __global__ __launch_bounds__(64, 2) void rnea_grad_idsva_pipe_kernel(const T* __
     backward(has_next ? tnext : t, !has_next);
 
     readback();
+#ifdef RBD_FDG_EXP_NOPROD          // timing experiment (results are wrong): no product
+    if constexpr (FDG) { sfor<0, FDC_NP>([&](auto S_) { constexpr int s_ = decltype(S_)::value; E[s_] += mk[s_]; }); }
+    if constexpr (false) {
+#else
     if constexpr (FDG) {
+#endif
       // E <- -Minv E (:1381-1383), column by column in place: 2 n columns x n^2 FMAs; Minv is symmetric (:799-804)
       sfor<0, GRAD_ROW>([&](auto C_) {
         constexpr int c = decltype(C_)::value;

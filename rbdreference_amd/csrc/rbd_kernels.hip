@@ -1805,6 +1805,113 @@ RBD_DEV void minv_cols_class(const T* wsl, T* tile, int dense, int lane, int& sl
   }
 }
 
+// ---- round 4: the column phase WITHOUT the forward sweep.  Minv = Psi^T D^-1 Psi (tools/check_minv_factorisation.py: the
+// operator factorisation minv_bpass + minv_fpass evaluate recursively, :630-783, exact at 2e-16 on every golden robot):
+//     Minv[i, j] = sum over k in anc(i) & anc(j) of  D_k m[k][i] m[k][j],     m[k][j] = minv_bpass's Minv[k, j], m[k][k] = 1 / D_k
+// so a column needs its BACKWARD sweep only (along its root path); the entries then follow from the table of all columns'
+// m -- which is the tile's upper triangle -- with a handful of FMAs per entry instead of one six-vector transform per
+// (column, body): the right arm's class of the 30-body robot 79 FMAs + LDS reads per lane instead of 28 dependent body steps.
+// Three steps with a block barrier between them (the table must be complete before it is read, and read before the final
+// values overwrite it):  _bwd -> table,  _fin -> registers,  _put -> tile (mirrored, :799-804).
+// TRI: the tile is the packed upper triangle (stride minv_tst), not the [rows][rows] square -- the table and the final values
+// then share their place and the mirror image is made by the flush (rbd_spatial.h: minv_own_rows_flush<..., TRI>).
+constexpr int minv_tst(int rt) { return (grp_rows(rt) * (grp_rows(rt) + 1) / 2) | 1; }
+template <class T, int RT, int CLS, int CPB = mcl_cpb(RT), bool TRI = false>
+RBD_DEV void minv_cols_class_bwd(const T* wsl, T* tile, int lane, int& slot_out, int& j_out, bool& spare_out, T (&wj)[N]) {
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT);
+  constexpr int LC = mcl_count(RT, CLS), TS = TRI ? minv_tst(RT) : minv_tso(RT);
+  static_assert(CPB * LC <= 64, "a class' columns of the block's configurations must fit one wave");
+  const int slot0 = lane / LC;
+  const bool spare = slot0 >= CPB;       // lanes beyond CPB * LC
+  const int slot = spare ? CPB - 1 : slot0;
+  const int kc = spare ? LC - 1 : lane - slot0 * LC;     // this lane's column within the class
+  constexpr int col0 = mcl_col(RT, CLS, 0);
+  int j = col0;
+  sfor<1, LC>([&](auto K) { constexpr int k = decltype(K)::value; constexpr int col = mcl_col(RT, CLS, k); j = sel(kc == k, col, j); });
+  slot_out = slot; j_out = j; spare_out = spare;
+  const T* myws = wsl + (slot * rows - row0) * MINV_WS;   // myws + i * MINV_WS = record of body i
+  T mcol[N];
+  sfor<row0, row0 + rows>([&](auto I) { mcol[decltype(I)::value] = T(0); wj[decltype(I)::value] = T(0); });
+  T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  T rec[N][MINV_WS];
+  constexpr int b0 = mcl_first_bwd(RT, CLS);
+  ws_read_lds(myws, b0, rec[b0]);
+  sfor_down<row0, row0 + rows>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if constexpr (mcl_bwd(RT, CLS, i)) {
+      constexpr int p = PARENT[i];
+      constexpr unsigned long long mask = subtree_mask(i);
+      constexpr int nx = mcl_next_bwd(RT, CLS, i);
+      if constexpr (nx >= 0) ws_read_lds(myws, nx, rec[nx]);
+      BodyCfg<T> bc;
+      sfor<0, 6>([&](auto R) { bc.U[decltype(R)::value] = rec[i][decltype(R)::value]; });
+      bc.Dinv = rec[i][6]; bc.s = rec[i][7]; bc.c = rec[i][8];
+      const bool insub = ((mask >> j) & 1ull) != 0;
+      T m = sel(j == i, bc.Dinv, -(bc.Dinv * S_dot<i>(Fj)));         // :700, :702-708
+      m = sel(insub, m, T(0));
+      mcol[i] = m;
+      wj[i] = bc.U[s_index(i)] * m;                                  // D_i m[i][j]   (D_i = S^T U_i, :698)
+      if constexpr (p >= 0) {
+        T t[6], y[6];
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(bc.U[r], m, Fj[r]); });   // :721-723
+        const JTrig<T> g{bc.s, bc.c};
+        xform_T<i>(g, t, y);                                                                                  // :724-726
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Fj[r] = sel(insub, y[r], Fj[r]); });
+      }
+      pin6(Fj);
+    }
+  });
+  // the table: column j of the tile's upper triangle, zeros included (rows that are no ancestors of j)
+  T* myt = tile + slot * TS;
+  const int jl = j - row0;
+  if (!spare) {
+    sfor<row0, row0 + rows>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (mcl_fwd(RT, CLS, i)) {
+        if (i <= j) myt[TRI ? tri_off(i - row0, jl, rows) : (i - row0) * rows + jl] = mcol[i];
+      }
+    });
+  }
+}
+template <class T, int RT, int CLS, bool TRI = false>
+RBD_DEV void minv_cols_class_fin(const T* tile, int slot, const T (&wj)[N], T (&acc)[N]) {
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT), TS = TRI ? minv_tst(RT) : minv_tso(RT);
+  const T* myt = tile + slot * TS;
+  sfor<row0, row0 + rows>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if constexpr (mcl_fwd(RT, CLS, i)) {
+      T a = T(0);
+      sfor<row0, i + 1>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        // k contributes to row i only if it is an ancestor-or-self of i, and to this class only if the class' backward
+        // sweep visits it (else w_j[k] = 0): both known at compile time
+        if constexpr (mcl_bwd(RT, CLS, k) && is_anc_or_self(k, i))
+          a = fma_(wj[k], myt[TRI ? tri_off(k - row0, i - row0, rows) : (k - row0) * rows + (i - row0)], a);
+      });
+      acc[i] = a;
+    }
+  });
+}
+template <class T, int RT, int CLS, bool TRI = false>
+RBD_DEV void minv_cols_class_put(T* tile, int dense, int slot, int j, bool spare, const T (&acc)[N]) {
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT), TS = TRI ? minv_tst(RT) : minv_tso(RT);
+  T* myt = tile + slot * TS;
+  const int jl = j - row0;
+  if (!spare) {
+    sfor<row0, row0 + rows>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (mcl_fwd(RT, CLS, i)) {
+        if constexpr (TRI) {
+          if (i <= j) myt[tri_off(i - row0, jl, rows)] = acc[i];
+        } else {
+          if (i <= j) myt[(i - row0) * rows + jl] = acc[i];
+          if (i < j) myt[jl * rows + (i - row0)] = sel(dense != 0, acc[i], T(0));
+        }
+      }
+    });
+  }
+}
+
 // A group with limbs: one block = mcl_cpb(RT) configurations, one wave per column class, shared records and tile.
 template <class T, int RT>
 RBD_DEV void minv_cols_limbs(const T* __restrict__ ws, long long B, int dense, T* __restrict__ Minv,
@@ -1837,6 +1944,7 @@ RBD_DEV void minv_cols_limbs(const T* __restrict__ ws, long long B, int dense, T
   __syncthreads();
   int slot = 0, j = row0;
   bool spare = true;                                       // a wave without a class in this group stays "spare"
+#ifdef RBD_MINV_EXP_FWD_SWEEP      // the reference's forward sweep per column (rounds 1-3), for A/B timing
   sfor<0, MINV_COLS_W>([&](auto W) {
     constexpr int w = decltype(W)::value;
     if constexpr (w <= NL) {
@@ -1844,6 +1952,24 @@ RBD_DEV void minv_cols_limbs(const T* __restrict__ ws, long long B, int dense, T
     }
   });
   __syncthreads();
+#else
+  T wj[N], accv[N];
+  sfor<0, MINV_COLS_W>([&](auto W) {
+    constexpr int w = decltype(W)::value;
+    if constexpr (w <= NL) { if (wave == w) minv_cols_class_bwd<T, RT, w>(wsl, tile, lane, slot, j, spare, wj); }
+  });
+  __syncthreads();
+  sfor<0, MINV_COLS_W>([&](auto W) {
+    constexpr int w = decltype(W)::value;
+    if constexpr (w <= NL) { if (wave == w) minv_cols_class_fin<T, RT, w>(tile, slot, wj, accv); }
+  });
+  __syncthreads();
+  sfor<0, MINV_COLS_W>([&](auto W) {
+    constexpr int w = decltype(W)::value;
+    if constexpr (w <= NL) { if (wave == w) minv_cols_class_put<T, RT, w>(tile, dense, slot, j, spare, accv); }
+  });
+  __syncthreads();
+#endif
 
   if (qdd_out != nullptr) {
     // forward_dynamics epilogue (:1371-1374): qdd = Minv (u - c); lane j owns row j of the dense tile.

@@ -24,6 +24,7 @@ namespace rbdk {
 
 constexpr int MF_W = MINV_COLS_W;          // waves per block
 constexpr int MF_CPB = 8;                  // configurations per block of a group with limbs
+constexpr int MF_XA = 8 * 6 * 6;           // scalars of one phase-A exchange area of such a block (8 configurations x 6 columns x 6)
 constexpr bool mf_group_ok(int rt) {
   if (minv_small_group(rt)) return true;
   if (mcl_limbs(rt) == 0) return false;
@@ -42,9 +43,14 @@ constexpr bool MINV_FUSED_OK = mf_ok();
 // the parks of phase A live in the tile's space (the tile is first written in phase B).  Small group: the group's
 // inertias + per wave max(exchange area, tile) + tau.
 constexpr size_t mf_max(size_t a, size_t b) { return a > b ? a : b; }
+// (round 4: the tile is the packed UPPER TRIANGLE of the group's block, 171 instead of 325 scalars per configuration for an
+// 18-body group, and the inertia table is symmetric-packed and lives in the space the tile takes over in phase B: 19.9 ->
+// 16.1 KB per block, i.e. TEN three-wave blocks per CU instead of eight -- with 60 VGPRs since the column phase lost its
+// forward sweep.  Those two extra slots per CU are where the small groups' blocks now run WHILE the big group's blocks are
+// resident instead of behind them: 24.0 -> 19 us for the 30-body robot at B = 16 384.)
 constexpr size_t mf_limbs_scalars(int rt) {
-  return (size_t)MF_CPB * grp_rows(rt) * MINV_WS + mf_max((size_t)MF_CPB * minv_tso(rt), (size_t)(2 * MF_W - 1) * 64 * 6) +
-         (size_t)grp_rows(rt) * 36;
+  return (size_t)MF_CPB * grp_rows(rt) * MINV_WS +
+         mf_max((size_t)MF_CPB * minv_tst(rt), (size_t)(2 * MF_W - 1) * MF_XA + (size_t)grp_rows(rt) * 21);
 }
 constexpr int MF_SMALL_WAVE = (64 * 6 > 8 * IA8_TS ? 64 * 6 : 8 * IA8_TS) + 64;   // scalars per wave of a small-group block
 constexpr size_t mf_small_scalars() { return (size_t)8 * 36 + (size_t)MF_W * MF_SMALL_WAVE; }
@@ -98,18 +104,27 @@ RBD_DEV void mf_segment_chain(const T* __restrict__ q, long long B, long long cf
     s_l[k] = sel(pris, qv, sv);
     c_l[k] = sel(pris, T(0), cv);
   });
+  // exchange areas hold the 6 x 6 values of the wave's 8 configurations compactly (the two idle lanes of a configuration's eight
+  // write nothing): MF_XA = 288 scalars per area instead of 64 x 6
+  const int x6 = (grp * 6 + cc) * 6;
+  // im_lds holds the group's inertias symmetric-packed (21 scalars per body): this lane's column cc of I_i is im_lds[i * 21 + so[r]]
+  int so[6];
+  sfor<0, 6>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    so[r] = r <= cc ? tri_off(r, cc, 6) : tri_off(cc, r, 6);
+  });
   T IAc[N][6];
   if constexpr (SEG == 0) {
     __syncthreads();                       // the limbs have parked what their roots hand to this stem
     sfor<0, N>([&](auto P) {
       constexpr int pp = decltype(P)::value;
       if constexpr (mcl_has(RT, 0, pp) && mf_has_limb_child(pp)) {
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[pp][r] = im_lds[pp * 36 + r * 6 + cc]; });
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[pp][r] = im_lds[pp * 21 + so[r]]; });
         sfor_down<0, N>([&](auto L) {      // descending: the order of the reference's loop (:732)
           constexpr int l = decltype(L)::value;
           if constexpr (limb_head(l) && PARENT[l] == pp) {
             constexpr int lk = limb_rank_in_group(l);
-            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[pp][r] += park[lk * 64 * 6 + lane * 6 + r]; });
+            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[pp][r] += park[lk * MF_XA + x6 + r]; });
           }
         });
       }
@@ -125,7 +140,7 @@ RBD_DEV void mf_segment_chain(const T* __restrict__ q, long long B, long long cf
       tri.s = grp8_bcast<idx % 8>(s_l[idx / 8]);
       tri.c = grp8_bcast<idx % 8>(c_l[idx / 8]);
       if constexpr (!has_child(i)) {
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[i][r] = im_lds[i * 36 + r * 6 + cc]; });
+        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; IAc[i][r] = im_lds[i * 21 + so[r]]; });
       }
       T U[6];
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[r] = grp8_bcast<si>(IAc[i][r]); });   // U = IA S (:697)
@@ -151,20 +166,20 @@ RBD_DEV void mf_segment_chain(const T* __restrict__ q, long long B, long long cf
         xform_T<i>(tri, col, y);                         // column c of A = X^T Ia
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; tr_lds[lane * 6 + r] = y[r]; });
+        if (c < 6) { sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; tr_lds[x6 + r] = y[r]; }); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         T row[6], z[6];
-        sfor<0, 6>([&](auto K) { constexpr int k = decltype(K)::value; row[k] = tr_lds[(grp * 8 + k) * 6 + cc]; });
+        sfor<0, 6>([&](auto K) { constexpr int k = decltype(K)::value; row[k] = tr_lds[(grp * 6 + k) * 6 + cc]; });
         xform_T<i>(tri, row, z);                         // column c of X^T Ia X (symmetric)
         if constexpr (SEG > 0 && !mcl_has(RT, SEG, p)) {  // the limb's root: parked for the stem's wave
-          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; park[(SEG - 1) * 64 * 6 + lane * 6 + r] = z[r]; });
+          if (c < 6) { sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; park[(SEG - 1) * MF_XA + x6 + r] = z[r]; }); }
         } else {
           constexpr bool pre = SEG == 0 && mf_has_limb_child(p);
           constexpr bool first = !pre && last_child_of(p) == i;
           sfor<0, 6>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            if constexpr (first) IAc[p][r] = im_lds[p * 36 + r * 6 + cc] + z[r]; else IAc[p][r] += z[r];
+            if constexpr (first) IAc[p][r] = im_lds[p * 21 + so[r]] + z[r]; else IAc[p][r] += z[r];
           });
           pin6(IAc[p]);
         }
@@ -178,26 +193,32 @@ RBD_DEV void mf_segment_chain(const T* __restrict__ q, long long B, long long cf
 template <class T, int RT>
 RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* __restrict__ Minv, const T* __restrict__ u_in,
                             const T* __restrict__ c_in, T* __restrict__ qdd_out, long long blk, T* smem) {
-  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT), NL = mcl_limbs(RT), TS = minv_tso(RT), NT = 64 * MF_W;
-  constexpr int TILE_SPACE = (int)mf_max((size_t)MF_CPB * TS, (size_t)(2 * MF_W - 1) * 64 * 6);
+  constexpr int row0 = grp_row0(RT), rows = grp_rows(RT), NL = mcl_limbs(RT), TS = minv_tst(RT), NT = 64 * MF_W;
   T* recs = smem;                                   // [8][rows][MINV_WS]
-  T* tile = recs + MF_CPB * rows * MINV_WS;         // [8][TS]   (phase B onwards)
-  T* tr_all = tile;                                 // [W][64 * 6]      phase A only: in the tile's space
-  T* park = tr_all + MF_W * 64 * 6;                 // [W - 1][64 * 6]  phase A only
-  T* im_lds = tile + TILE_SPACE - row0 * 36;        // im_lds[i * 36 + ..] for the group's bodies i
+  T* tile = recs + MF_CPB * rows * MINV_WS;         // [8][TS]   (phase B onwards): packed upper triangles
+  T* tr_all = tile;                                 // [W][MF_XA]       phase A only: in the tile's space
+  T* park = tr_all + MF_W * MF_XA;                  // [W - 1][MF_XA]   phase A only
+  T* im_lds = park + (MF_W - 1) * MF_XA - row0 * 21;    // phase A only: im_lds[i * 21 + packed (r, c)] for the group's bodies i
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const long long cfg0 = blk * MF_CPB;
   const long long rem = B - cfg0;
   const int nvalid = rem < MF_CPB ? (int)rem : MF_CPB;
-  for (int k = tid; k < rows * 36; k += NT) im_lds[row0 * 36 + k] = T(IM[row0 + k / 36][k % 36]);   // this group's inertias
+  {
+    constexpr int TR[21] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5};
+    constexpr int TC[21] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5};
+    for (int k = tid; k < rows * 21; k += NT) {     // this group's inertias, upper triangles
+      const int e = k % 21;
+      im_lds[row0 * 21 + k] = T(IM[row0 + k / 21][TR[e] * 6 + TC[e]]);
+    }
+  }
   __syncthreads();
   // ---- phase A: one wave per segment (waves beyond the group's segments only keep the barrier count) -------------
   bool ran = false;
   sfor<0, MF_W>([&](auto W) {
     constexpr int w = decltype(W)::value;
     if constexpr (w <= NL) {
-      if (wave == w) { mf_segment_chain<T, RT, w>(q, B, cfg0, lane, recs, tr_all + w * 64 * 6, im_lds, park); ran = true; }
+      if (wave == w) { mf_segment_chain<T, RT, w>(q, B, cfg0, lane, recs, tr_all + w * MF_XA, im_lds, park); ran = true; }
     }
   });
   if (!ran) __syncthreads();
@@ -205,13 +226,21 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
   // ---- phase B: one wave per column class ---------------------------------------------------------------------------
   int slot = 0, j = row0;
   bool spare = true;
+  // backward sweeps -> table (the tile's upper triangle) | entries from the table (Minv = Psi^T D^-1 Psi) | final values
+  T wj[N], accv[N];
   sfor<0, MF_W>([&](auto W) {
     constexpr int w = decltype(W)::value;
-    if constexpr (w <= NL) {
-#ifndef RBD_MF_EXP_NOB            // timing experiment: no column phase (results are wrong)
-      if (wave == w) minv_cols_class<T, RT, w, MF_CPB>(recs, tile, dense, lane, slot, j, spare);
-#endif
-    }
+    if constexpr (w <= NL) { if (wave == w) minv_cols_class_bwd<T, RT, w, MF_CPB, true>(recs, tile, lane, slot, j, spare, wj); }
+  });
+  __syncthreads();
+  sfor<0, MF_W>([&](auto W) {
+    constexpr int w = decltype(W)::value;
+    if constexpr (w <= NL) { if (wave == w) minv_cols_class_fin<T, RT, w, true>(tile, slot, wj, accv); }
+  });
+  __syncthreads();
+  sfor<0, MF_W>([&](auto W) {
+    constexpr int w = decltype(W)::value;
+    if constexpr (w <= NL) { if (wave == w) minv_cols_class_put<T, RT, w, true>(tile, dense, slot, j, spare, accv); }
   });
   __syncthreads();
   if (qdd_out != nullptr) {
@@ -219,9 +248,14 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
     if (!spare && slot < nvalid) tau[j] = u_in[(cfg0 + slot) * N + j] - c_in[(cfg0 + slot) * N + j];
     __syncthreads();
     if (!spare && slot < nvalid) {
-      const T* myt = tile + slot * TS + (j - row0) * rows;
+      const T* myt = tile + slot * TS;              // row j of the symmetric block from the packed upper triangle
+      const int jl = j - row0;
       T o = T(0);
-      sfor<row0, row0 + rows>([&](auto K) { constexpr int k = decltype(K)::value; o = fma_(myt[k - row0], tau[k], o); });
+      sfor<row0, row0 + rows>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const int off = (k - row0) <= jl ? tri_off(k - row0, jl, rows) : tri_off(jl, k - row0, rows);
+        o = fma_(myt[off], tau[k], o);
+      });
       qdd_out[(cfg0 + slot) * N + j] = o;
     }
   }
@@ -235,12 +269,15 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
     auto elem = [&](int cfg, int e) -> T {
       const int r = e / N;
       const int cx = e - r * N - row0;
-      const bool own = cx >= 0 && cx < rows;
-      const T x = tile[cfg * TS + r * rows + (own ? cx : 0)];
+      bool own = cx >= 0 && cx < rows;
+      const int cc2 = own ? cx : r;
+      const int off = cc2 >= r ? tri_off(r, cc2, rows) : tri_off(cc2, r, rows);
+      own = own && (dense != 0 || cc2 >= r);
+      const T x = tile[cfg * TS + off];
       return own ? x : T(0);
     };
     if constexpr (minv_piece_flush<T>(RT)) {
-      minv_own_rows_flush<T, row0, rows, MF_CPB, TS, NT>(tile, gdst, tid, nvalid);
+      minv_own_rows_flush<T, row0, rows, MF_CPB, TS, NT, true>(tile, gdst, tid, nvalid, dense);
     } else {
       const int total = nvalid * RW;
 #pragma unroll 4

@@ -92,8 +92,7 @@ RBD_DEV void ia8_group(const T* __restrict__ q, long long B, T* __restrict__ ws,
   const bool fused = SMALL && fuse_small != 0;
   // this lane's column of a small group (lanes c >= rows repeat the last one and store nothing)
   const int jc = R0 + (c < RN ? c : RN - 1);
-  T Us[N][6], Ds[N], mcol[N];
-  JTrig<T> trs[N];
+  T mcol[N], wj[N];                              // column jc: m[i][jc] = minv_bpass's Minv[i, jc], and D_i m[i][jc]
   T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   sfor_down<grp_row0(rt), grp_row0(rt) + grp_rows(rt)>([&](auto I) {
     constexpr int i = decltype(I)::value;
@@ -127,13 +126,12 @@ RBD_DEV void ia8_group(const T* __restrict__ q, long long B, T* __restrict__ ws,
     if constexpr (SMALL) {
       if (fused) {
         // backward step of column jc at body i (:700-726), as in minv_cols_group
-        sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; Us[i][r] = U[r]; });
-        Ds[i] = Dinv; trs[i] = tri;
         constexpr unsigned long long mask = subtree_mask(i);
         const bool insub = ((mask >> jc) & 1ull) != 0;
         T m = sel(jc == i, Dinv, -(Dinv * S_dot<i>(Fj)));
         m = sel(insub, m, T(0));
         mcol[i] = m;
+        wj[i] = U[si] * m;                               // D_i m[i][jc]   (D_i = S^T U_i, :698)
         if constexpr (p >= 0) {
           T t[6], y[6];
           sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = fma_(U[r], m, Fj[r]); });
@@ -171,30 +169,32 @@ RBD_DEV void ia8_group(const T* __restrict__ q, long long B, T* __restrict__ ws,
   });
   if constexpr (SMALL) {
     if (fused) {
-      // ---- forward sweep of column jc (:760-781) from the records kept in registers -------------------------------
-      T Ff[N][6];
-      sfor<R0, R0 + RN>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        constexpr int p = PARENT[i];
-        constexpr int si = s_index(i);
-        if constexpr (p < 0) {
-          sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
-          Ff[i][si] = mcol[i];
-        } else {
-          xform<i>(trs[i], Ff[p], Ff[i]);
-          const T m = fma_(-Ds[i], dot6(Us[i], Ff[i]), mcol[i]);
-          mcol[i] = m;
-          Ff[i][si] += m;
-        }
-      });
-      // ---- the column into the tile, mirrored (:799-804) -----------------------------------------------------------
+      // ---- no forward sweep (round 4): Minv = Psi^T D^-1 Psi (rbd_kernels.hip, minv_cols_class_bwd; exact, tools/
+      //      check_minv_factorisation.py):  Minv[i, jc] = sum over k in anc(i) & anc(jc) of (D_k m[k][jc]) m[k][i].  The table of
+      //      all columns' m is the tile's upper triangle; U, 1/D, sin / cos of the group's bodies need not stay in registers.
       T* myt = tile_s + grp * IA8_TS;                    // myt[(i - R0) * RN + (col - R0)]
       const int jl = jc - R0;
       if (c < RN) {
+        sfor<R0, R0 + RN>([&](auto I) { constexpr int i = decltype(I)::value; if (i <= jc) myt[(i - R0) * RN + jl] = mcol[i]; });
+      }
+      __syncthreads();
+      T accv[N];
+      sfor<R0, R0 + RN>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        T a = T(0);
+        sfor<R0, i + 1>([&](auto K) {
+          constexpr int k = decltype(K)::value;
+          if constexpr (is_anc_or_self(k, i)) a = fma_(wj[k], myt[(k - R0) * RN + (i - R0)], a);
+        });
+        accv[i] = a;
+      });
+      __syncthreads();
+      // ---- the column into the tile, mirrored (:799-804) -----------------------------------------------------------
+      if (c < RN) {
         sfor<R0, R0 + RN>([&](auto I) {
           constexpr int i = decltype(I)::value;
-          if (i <= jc) myt[(i - R0) * RN + jl] = mcol[i];
-          if (i < jc) myt[jl * RN + (i - R0)] = sel(dense != 0, mcol[i], T(0));
+          if (i <= jc) myt[(i - R0) * RN + jl] = accv[i];
+          if (i < jc) myt[jl * RN + (i - R0)] = sel(dense != 0, accv[i], T(0));
         });
       }
       __syncthreads();

@@ -102,54 +102,60 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && grad_max_rows() <= 8) ? 2 : 
         }
       });
     }
-    // ---- one column of Minv at a time ----------------------------------------------------------------
-    sfor<row0, row0 + rows>([&](auto JC) {
-      constexpr int jc = decltype(JC)::value;
-      T mcol[N];
-      sfor<row0, jc + 1>([&](auto I) { mcol[decltype(I)::value] = T(0); });
-      // backward sweep along the root path of jc (:700-726)
-      T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-      sfor_down<row0, jc + 1>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (is_anc_or_self(i, jc)) {
-          constexpr int p = PARENT[i];
-          T m;
-          if constexpr (i == jc) m = Dinv[i];
-          else m = -(Dinv[i] * S_dot<i>(Fj));
-          mcol[i] = m;
-          if constexpr (p >= 0) {
-            T t[6], y[6];
-            sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = (i == jc) ? U[i][r] * m : fma_(U[i][r], m, Fj[r]); });
-            xform_T<i>(tr[i], t, y);
-            sfor<0, 6>([&](auto R) { Fj[decltype(R)::value] = y[decltype(R)::value]; });
+    // ---- Minv of the group.  Backward sweeps only (:700-726): column jc climbs its root path and leaves
+    //      m[k][jc] = minv_bpass's Minv[k, jc] for every ancestor-or-self k.  The reference's forward pass (:760-781: for every
+    //      column a six-vector transform per body of the group) is replaced by the factorisation it evaluates,
+    //          Minv[i, j] = sum over k in anc(i) & anc(j) of  D_k m[k][i] m[k][j],      m[k][k] = 1 / D_k
+    //      (exact: 2e-16 against the reference's Minv on every golden robot, tools/check_minv_factorisation.py) -- scalar FMAs
+    //      over COMMON ANCESTORS, all resolved at compile time; unrelated pairs of one root share ancestors too. ----------
+    {
+      T Mb[N][N];
+      sfor<row0, row0 + rows>([&](auto JC) {
+        constexpr int jc = decltype(JC)::value;
+        T Fj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        sfor_down<row0, jc + 1>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          if constexpr (is_anc_or_self(i, jc)) {
+            constexpr int p = PARENT[i];
+            T m;
+            if constexpr (i == jc) m = Dinv[i];
+            else m = -(Dinv[i] * S_dot<i>(Fj));
+            Mb[i][jc] = m;
+            if constexpr (p >= 0) {
+              T t[6], y[6];
+              sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; t[r] = (i == jc) ? U[i][r] * m : fma_(U[i][r], m, Fj[r]); });
+              xform_T<i>(tr[i], t, y);
+              sfor<0, 6>([&](auto R) { Fj[decltype(R)::value] = y[decltype(R)::value]; });
+            }
           }
-        }
+        });
       });
-      // forward sweep over the bodies i <= jc of the group (:760-781)
-      T Ff[N][6];
-      sfor<row0, jc + 1>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        constexpr int p = PARENT[i];
-        constexpr int si = s_index(i);
-        if constexpr (p < 0) {
-          sfor<0, 6>([&](auto R) { Ff[i][decltype(R)::value] = T(0); });
-          Ff[i][si] = mcol[i];
-        } else {
-          xform<i>(tr[i], Ff[p], Ff[i]);
-          const T m = fma_(-Dinv[i], dot6(U[i], Ff[i]), mcol[i]);
-          mcol[i] = m;
-          Ff[i][si] += m;
-        }
+      T W[N][N];                                                  // W[k][i] = D_k m[k][i], k a proper ancestor of i (D_k = S^T U_k)
+      sfor<row0, row0 + rows>([&](auto I) {
+        sfor<row0, row0 + rows>([&](auto K) {
+          constexpr int i = decltype(I)::value, k = decltype(K)::value;
+          if constexpr (k != i && is_anc_or_self(k, i)) W[k][i] = U[k][s_index(k)] * Mb[k][i];
+        });
       });
-      // column jc is final for rows i <= jc: LDS image (with the mirror, :799-804) and Minv (u - c)
-      sfor<row0, jc + 1>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        my[i * N + jc] = mcol[i];
-        if constexpr (i < jc) my[jc * N + i] = sel(dense != 0, mcol[i], T(0));
-        qacc[i] = fma_(mcol[i], tau[jc], qacc[i]);
-        if constexpr (i < jc) qacc[jc] = fma_(mcol[i], tau[i], qacc[jc]);
+      sfor<row0, row0 + rows>([&](auto J) {
+        sfor<row0, row0 + rows>([&](auto I) {
+          constexpr int i = decltype(I)::value, j = decltype(J)::value;
+          if constexpr (i <= j) {
+            T acc = T(0);
+            bool any = false;
+            if constexpr (is_anc_or_self(i, j)) { acc = Mb[i][j]; any = true; }          // k = i: D_i m[i][i] m[i][j] = m[i][j]
+            sfor<row0, row0 + rows>([&](auto K) {
+              constexpr int k = decltype(K)::value;
+              if constexpr (k != i && is_anc_or_self(k, i) && is_anc_or_self(k, j)) { acc = any ? fma_(W[k][i], Mb[k][j], acc) : W[k][i] * Mb[k][j]; any = true; }
+            });
+            my[i * N + j] = acc;
+            if constexpr (i < j) my[j * N + i] = sel(dense != 0, acc, T(0));
+            qacc[i] = fma_(acc, tau[j], qacc[i]);
+            if constexpr (i < j) qacc[j] = fma_(acc, tau[i], qacc[j]);
+          }
+        });
       });
-    });
+    }
     // columns of other groups are structural zeros
     sfor<row0, row0 + rows>([&](auto I) {
       sfor<0, N>([&](auto C) {

@@ -318,8 +318,11 @@ RBD_DEV void rnea_fwd_body(const JTrig<T>& g, T qd, T qdd, T grav, const T (&vp)
 // "own column" flags are computed ONCE, and every pass is four LDS reads, four selects and one store.  (The generic
 // loop  g = tid, tid + NT, ...  divides by RN * N / 4 and by N four times in every iteration: 50 instructions per piece,
 // a fifth of the one-launch kernel's instruction stream and 6 of its 29 us on the 30-body robot.)
-template <class T, int R0, int RN, int NCFG, int TS, int NT>
-RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid) {
+// TRI: the tile holds only the UPPER TRIANGLE of the group's symmetric block, packed row-major (tri_off), TS = its stride;
+// the mirror image (:799-804) is generated here -- or zeros below the diagonal when `dense` == 0.
+RBD_DEV constexpr int tri_off(int a, int b, int rn) { return a * rn - a * (a - 1) / 2 + (b - a); }     // a <= b
+template <class T, int R0, int RN, int NCFG, int TS, int NT, bool TRI = false>
+RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid, int dense = 1) {
   constexpr int VE = 16 / (int)sizeof(T);
   static_assert((RN * N) % VE == 0, "16-byte pieces");
   typedef T V __attribute__((ext_vector_type(VE)));
@@ -338,7 +341,13 @@ RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid) {
           const int r = e / N;
           const int cidx = e - r * N - R0;
           own[i] = cidx >= 0 && cidx < RN;
-          off[i] = r * RN + (own[i] ? cidx : 0);
+          if constexpr (TRI) {
+            const int cx = own[i] ? cidx : r;
+            off[i] = cx >= r ? tri_off(r, cx, RN) : tri_off(cx, r, RN);
+            own[i] = own[i] && (dense != 0 || cx >= r);
+          } else {
+            off[i] = r * RN + (own[i] ? cidx : 0);
+          }
         });
         V buf[PASSES];
         sfor<0, PASSES>([&](auto P_) {
@@ -361,8 +370,16 @@ RBD_DEV void minv_own_rows_flush(const T* tile, T* gdst, int tid, int nvalid) {
   auto elem = [&](int cfg, int e) -> T {                 // (row e / N, column e % N): own columns from the tile, the rest zero
     const int r = e / N;
     const int cidx = e - r * N - R0;
-    const bool own = cidx >= 0 && cidx < RN;
-    const T x = tile[cfg * TS + r * RN + (own ? cidx : 0)];
+    bool own = cidx >= 0 && cidx < RN;
+    int o;
+    if constexpr (TRI) {
+      const int cx = own ? cidx : r;
+      o = cx >= r ? tri_off(r, cx, RN) : tri_off(cx, r, RN);
+      own = own && (dense != 0 || cx >= r);
+    } else {
+      o = r * RN + (own ? cidx : 0);
+    }
+    const T x = tile[cfg * TS + o];
     return own ? x : T(0);
   };
   const int total = nvalid * RV;
