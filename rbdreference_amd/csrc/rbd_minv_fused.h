@@ -44,10 +44,10 @@ constexpr bool MINV_FUSED_OK = mf_ok();
 // inertias + per wave max(exchange area, tile) + tau.
 constexpr size_t mf_max(size_t a, size_t b) { return a > b ? a : b; }
 // (round 4: the tile is the packed UPPER TRIANGLE of the group's block, 171 instead of 325 scalars per configuration for an
-// 18-body group, and the inertia table is symmetric-packed and lives in the space the tile takes over in phase B: 19.9 ->
-// 16.1 KB per block, i.e. TEN three-wave blocks per CU instead of eight -- with 60 VGPRs since the column phase lost its
-// forward sweep.  Those two extra slots per CU are where the small groups' blocks now run WHILE the big group's blocks are
-// resident instead of behind them: 24.0 -> 19 us for the 30-body robot at B = 16 384.)
+// 18-body group, the inertia table is symmetric-packed and lives in the space the tile takes over in phase B, and the exchange
+// areas hold 6 x 6 values per configuration without the idle lanes' slots: 19.9 -> 14.2 KB per block, i.e. TEN three-wave blocks
+// per CU instead of eight, with 60 VGPRs since the column phase lost its forward sweep.  Measured: no change at B = 16 384
+// (all 2 048 + 1 366 blocks were co-resident before, too), 777 -> 689-733 us at B = 524 288.)
 constexpr size_t mf_limbs_scalars(int rt) {
   return (size_t)MF_CPB * grp_rows(rt) * MINV_WS +
          mf_max((size_t)MF_CPB * minv_tst(rt), (size_t)(2 * MF_W - 1) * MF_XA + (size_t)grp_rows(rt) * 21);
@@ -144,7 +144,7 @@ RBD_DEV void mf_segment_chain(const T* __restrict__ q, long long B, long long cf
       }
       T U[6];
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[r] = grp8_bcast<si>(IAc[i][r]); });   // U = IA S (:697)
-      const T Dinv = T(1) / U[si];                                                                          // :698,:700
+      const T Dinv = rcp_inertia(U[si]);                                                                          // :698,:700
       {   // record {U[6], 1/D, s, c, 0, 0, 0} of (configuration grp, body i) into LDS: lanes 0..VPB-1 one 16-byte piece each
         constexpr int VE = 16 / sizeof(T);
         constexpr int VPB = MINV_WS / VE;
@@ -223,6 +223,9 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
   });
   if (!ran) __syncthreads();
   __syncthreads();                                  // every record of the block is in LDS
+#if defined(RBD_MF_EXP_STOP) && RBD_MF_EXP_STOP == 1     // timing experiments (tools/pmc_atlas_variants.sh): the block ends after phase A /
+  if (dense != 12345) return;                           // the sweeps / the entries; results are wrong
+#endif
   // ---- phase B: one wave per column class ---------------------------------------------------------------------------
   int slot = 0, j = row0;
   bool spare = true;
@@ -233,11 +236,17 @@ RBD_DEV void mf_limbs_group(const T* __restrict__ q, long long B, int dense, T* 
     if constexpr (w <= NL) { if (wave == w) minv_cols_class_bwd<T, RT, w, MF_CPB, true>(recs, tile, lane, slot, j, spare, wj); }
   });
   __syncthreads();
+#if defined(RBD_MF_EXP_STOP) && RBD_MF_EXP_STOP == 2
+  if (dense != 12345) return;
+#endif
   sfor<0, MF_W>([&](auto W) {
     constexpr int w = decltype(W)::value;
     if constexpr (w <= NL) { if (wave == w) minv_cols_class_fin<T, RT, w, true>(tile, slot, wj, accv); }
   });
   __syncthreads();
+#if defined(RBD_MF_EXP_STOP) && RBD_MF_EXP_STOP == 3
+  if (dense != 12345) return;
+#endif
   sfor<0, MF_W>([&](auto W) {
     constexpr int w = decltype(W)::value;
     if constexpr (w <= NL) { if (wave == w) minv_cols_class_put<T, RT, w, true>(tile, dense, slot, j, spare, accv); }

@@ -26,7 +26,11 @@ template <int L>
 RBD_DEV int grp8_bcast_i(int x) {
   constexpr int q = L % 4;
   constexpr int quad = q | (q << 2) | (q << 4) | (q << 6);          // quad_perm [q, q, q, q]
+#ifdef RBD_EXP_DPP_TIED
   const int x1 = __builtin_amdgcn_update_dpp(x, x, quad, 0xF, 0xF, false);
+#else
+  const int x1 = __builtin_amdgcn_mov_dpp(x, quad, 0xF, 0xF, true);   // every lane written: no tied `old` operand, so no copy of x when x stays live
+#endif
   return __builtin_amdgcn_update_dpp(x1, x1, 0x141 /* row_half_mirror */, 0xF, L < 4 ? 0xA : 0x5, false);
 }
 template <int L>
@@ -106,7 +110,7 @@ RBD_DEV void ia8_group(const T* __restrict__ q, long long B, T* __restrict__ ws,
     }
     T U[6];
     sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[r] = grp8_bcast<si>(IAc[i][r]); });   // U = IA S (:697)
-    const T Dinv = T(1) / U[si];                                                                          // :698,:700
+    const T Dinv = rcp_inertia(U[si]);                                                                          // :698,:700
     // record {U[6], 1/D, s, c, 0, 0, 0}: every lane of the group holds all of it, so lanes 0..VPB-1 each
     // store one 16-byte piece -> one store instruction per body covers the block's 8 x 48 contiguous bytes
     {

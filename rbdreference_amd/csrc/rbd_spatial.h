@@ -49,6 +49,19 @@ RBD_DEV T sel(bool c, T a, T b) { return c ? a : b; }
 
 RBD_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RBD_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// 1 / d for a joint-space inertia D = S^T IA S (positive, well scaled: no denormal / overflow handling needed).  fp32: v_rcp_f32
+// (1 ulp) + one Newton step, three dependent instructions instead of the ten of an IEEE division (v_div_scale x 2, v_rcp,
+// four fma, v_div_fmas, v_div_fixup) on the critical path of every body step of the eight-lane recursions; NaN stays NaN.
+// fp64 keeps the division.
+RBD_DEV float rcp_inertia(float d) {
+#ifdef RBD_EXP_TRUE_DIV
+  return 1.0f / d;
+#else
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+#endif
+}
+RBD_DEV double rcp_inertia(double d) { return 1.0 / d; }
 
 // ---- compile-time tree queries ---------------------------------------------------------------
 constexpr bool is_anc_or_self(int a, int j) {
