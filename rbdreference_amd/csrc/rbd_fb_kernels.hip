@@ -136,11 +136,13 @@ int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gra
   }
 }
 template <class T>
-int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
+int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream, const T* u = nullptr, const T* cbias = nullptr, T* qdd = nullptr,
+                   bool* fused_qdd = nullptr) {
   using namespace rbdk;
+  if (fused_qdd) *fused_qdd = false;
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
-  if (!q || !Minv) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
+  if (!q || (!Minv && !qdd)) return fail(RBD_ERR_ARG, "rbd_minv: q and Minv must be non-null");
   if (misaligned(Minv)) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be 16-byte aligned");
   if constexpr (minv_fbm_ok<T>()) {
     // one wave per subtree of the base (rbd_fb_minv.h); RBD_OPT_MINV_PHASE_A = LANE keeps the four-lanes kernel
@@ -151,11 +153,14 @@ int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream) {
       auto km = minv_fbm_kernel<T>;
       int rcm;
       if ((rcm = ensure_lds(km, ldsm)) != 0) return rcm;
-      hipLaunchKernelGGL(km, dim3((unsigned)nb), dim3(64 * FBW_W), ldsm, (hipStream_t)stream, q, (long long)B, dense, Minv);
+      // with u, c, qdd: qdd = Minv (u - c) leaves the same launch (rbd_fb_minv.h); Minv may then be null
+      hipLaunchKernelGGL(km, dim3((unsigned)nb), dim3(64 * FBW_W), ldsm, (hipStream_t)stream, q, (long long)B, dense, Minv, u, cbias, qdd);
+      if (fused_qdd) *fused_qdd = qdd != nullptr;
       hipError_t em = hipGetLastError();
       return em == hipSuccess ? 0 : hip_fail(em, "rbd_minv (floating base, wave per subtree) launch");
     }
   }
+  if (!Minv) return fail(RBD_ERR_ARG, "rbd_minv: Minv must be non-null");
   const int64_t blocks = (B + 64 / FB_MINV_L - 1) / (64 / FB_MINV_L);
   if (blocks > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_minv: B too large");
   constexpr size_t lds = minv_fb_lds_bytes<T>();
@@ -182,7 +187,12 @@ int fd_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* q
   T* Mi = reinterpret_cast<T*>(w + off_m);
   int rc;
   if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
-  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream)) != 0) return rc;                                               // :1373
+  // :1373-1374 in one launch where the wave-per-subtree kernel serves the robot: qdd = Minv (u - c) from the columns in
+  // registers, the matrix itself is never written (Minv = nullptr); else minv into the workspace + the product kernel
+  bool fused = false;
+  const bool wave_kernel = minv_fbm_ok<T>() && rbd_option(RBD_OPT_MINV_PHASE_A) != RBD_MINV_PHASE_A_LANE;
+  if ((rc = minv_fb_launch<T>(q, B, 1, wave_kernel ? (T*)nullptr : Mi, stream, u, (const T*)c, qdd, &fused)) != 0) return rc;
+  if (fused) return 0;
   const int64_t ab = ((int64_t)B * NV + 255) / 256;
   if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B too large");
   hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
@@ -311,10 +321,13 @@ int fdg_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* 
   T* qdd = qdd_out ? qdd_out : qdd_ws;
   int rc;
   if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
-  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream)) != 0) return rc;                                               // :1373, :1381
-  const int64_t ab = ((int64_t)B * NV + 255) / 256;
-  if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
-  hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
+  bool fused = false;
+  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream, u, (const T*)c, qdd, &fused)) != 0) return rc;                   // :1373, :1381 (+ :1374 where fused)
+  if (!fused) {
+    const int64_t ab = ((int64_t)B * NV + 255) / 256;
+    if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");
+    hipLaunchKernelGGL((fb_apply_kernel<T>), dim3((unsigned)ab), dim3(256), 0, (hipStream_t)stream, (const T*)Mi, u, (const T*)c, (long long)B, qdd);   // :1374
+  }
   if ((rc = grad_fb_launch<T>("rbd_forward_dynamics_grad", q, qd, (const T*)qdd, gravity, 0, B, (T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)nullptr, dc, stream)) != 0) return rc;   // :1378
   constexpr int MMC = negmm_cfgs<T, NV>();
   const int64_t mb = (B + MMC - 1) / MMC;

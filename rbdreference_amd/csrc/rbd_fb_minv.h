@@ -16,6 +16,10 @@
 //             columns and their mirror entries, wave 0 the base block), flat 16-byte copies of whole lines.
 // Same arithmetic per column as minv_fb_kernel, so the two agree to rounding; 1.8x fewer instructions per
 // configuration (the recursion is done once, not four times).
+// forward dynamics (:1371-1374): with u, c the kernel also emits qdd = Minv (u - c) -- every wave multiplies the columns it
+// holds in registers (and their mirror entries) with tau, the partial sums meet in the lane-private LDS slots the records
+// leave free -- and with Minv == nullptr it skips the image and the 4 nv^2-byte matrix altogether (round 3 ran a separate
+// kernel that re-read the dense Minv for this product: 21 us of a 58 us forward_dynamics at B = 65 536).
 #pragma once
 #include "rbd_fb.h"
 #include "rbd_fb_world.h"      // FBW_W, fbw_wave_of (the wave <-> subtree assignment of the gradient kernel)
@@ -46,7 +50,9 @@ constexpr int fbm_sym_index(int r, int c) {                 // r <= c -> 0..20
 }
 
 template <class T>
-__global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __restrict__ q, long long B, int dense, T* __restrict__ Minv) {
+__global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __restrict__ q, long long B, int dense, T* __restrict__ Minv,
+                                                                  const T* __restrict__ u_in = nullptr, const T* __restrict__ c_in = nullptr,
+                                                                  T* __restrict__ qdd_out = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* img = reinterpret_cast<T*>(smem_raw);                                   // [FBM_Q][NV * NV]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -133,6 +139,12 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __rest
   // [k-th column of this wave][row]: indexed by the column's ORDINAL within its wave -- indexed by body, every wave
   // would hold registers for every other wave's columns too (the branches below are per wave at run time)
   T colv[fbm_max_cols()][NV];
+  const bool fd = qdd_out != nullptr;                            // (uniform over the launch)
+  T tau[NV], qacc[NV];
+  sfor<0, NV>([&](auto R) { constexpr int r = decltype(R)::value; tau[r] = fd ? u_in[b * NV + r] - c_in[b * NV + r] : T(0); qacc[r] = T(0); });
+  if (fd && wave == 0) {                                         // the base block times tau[0:6]
+    sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; qacc[r] = fma_(fb6[r][c], tau[c], qacc[r]); }); });
+  }
   sfor<1, N>([&](auto JB) {
     constexpr int jb = decltype(JB)::value;
     if (wave == fbw_wave_of(jb)) {
@@ -179,8 +191,33 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __rest
       });
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; colv[fbm_col_ord(jb)][r] = Ff[0][r]; });
       sfor<1, N>([&](auto I) { constexpr int i = decltype(I)::value; colv[fbm_col_ord(jb)][i + 5] = mcol[i]; });
+      if (fd) {     // column j = jb + 5 of the symmetric matrix: rows r <= j, and their mirror entries in row j
+        constexpr int j = jb + 5;
+        sfor<0, NV>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          if constexpr (r <= j) {
+            qacc[r] = fma_(colv[fbm_col_ord(jb)][r], tau[j], qacc[r]);
+            if constexpr (r < j) qacc[j] = fma_(colv[fbm_col_ord(jb)][r], tau[r], qacc[j]);
+          }
+        });
+      }
     }
   });
+  if (fd) {
+    static_assert(FBW_W * NV <= FBM_PRIV, "qdd partial sums: lane-private slots");
+    __syncthreads();                                             // every wave has read the last record: the slots are free
+    sfor<0, NV>([&](auto R) { constexpr int r = decltype(R)::value; priv[(wave * NV + r) * 64] = qacc[r]; });
+    __syncthreads();
+    if (wave == 0 && lane < nvalid) {
+      sfor<0, NV>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        T o = qacc[r];
+        sfor<1, FBW_W>([&](auto W_) { o += priv[(decltype(W_)::value * NV + r) * 64]; });
+        qdd_out[b * NV + r] = o;
+      });
+    }
+  }
+  if (Minv == nullptr) return;                                   // forward_dynamics: the matrix itself is not wanted
   // ---- output: 16 configurations at a time ---------------------------------------------------------------------------
   constexpr int VE = 16 / sizeof(T);
   typedef T V __attribute__((ext_vector_type(VE)));
