@@ -2126,9 +2126,9 @@ __attribute__((visibility("hidden"))) int rbd_grad_noqdd_f64(const double* q, co
 __attribute__((visibility("hidden"))) int rbd_grad_cols_noqdd_f32(const float* q, const float* qd, float gravity, int use_damping, int64_t B, float* c, float* v, float* a, float* f, float* dc_du, void* stream);
 __attribute__((visibility("hidden"))) int rbd_grad_cols_noqdd_f64(const double* q, const double* qd, double gravity, int use_damping, int64_t B, double* c, double* v, double* a, double* f, double* dc_du, void* stream);
 __attribute__((visibility("hidden"))) int rbd_minv_fd_f32(const float* q, int64_t B, float* Minv, void* workspace, size_t wsb,
-                                                          void* stream, const float* u, const float* c, float* qdd);
+                                                          void* stream, const float* u, const float* c, float* qdd, const float* qd, float gravity);
 __attribute__((visibility("hidden"))) int rbd_minv_fd_f64(const double* q, int64_t B, double* Minv, void* workspace, size_t wsb,
-                                                          void* stream, const double* u, const double* c, double* qdd);
+                                                          void* stream, const double* u, const double* c, double* qdd, const double* qd, double gravity);
 }
 
 namespace {
@@ -2663,7 +2663,7 @@ int grad_kernel_name(int64_t B, char* buf, size_t len) {
 #ifdef RBD_NEED_MINV
 template <class T>
 int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspace, size_t wsb, void* stream,
-                const T* u = nullptr, const T* cbias = nullptr, T* qdd = nullptr) {
+                const T* u = nullptr, const T* cbias = nullptr, T* qdd = nullptr, const T* qd = nullptr, T gravity = T(0)) {
   using namespace rbdk;
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
   if (B == 0) return 0;
@@ -2677,11 +2677,15 @@ int minv_launch(const T* q, int64_t B, int output_dense, T* Minv, void* workspac
     auto k = minv_lane_kernel<T>;
     int rc;
     if ((rc = ensure_lds(k, lds)) != 0) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, (long long)B, output_dense, Minv, u, cbias, qdd);
+    // (qd given instead of c: the kernel computes the bias force itself, rbd_minv_lane.h)
+    if (qdd && !cbias && !qd) return fail(RBD_ERR_ARG, "rbd_minv (forward dynamics): c or qd must be given");
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, q, (long long)B, output_dense, Minv, u, cbias, qdd,
+                       cbias ? (const T*)nullptr : qd, gravity);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "rbd_minv launch");
     return 0;
   } else {
+  if (qdd && !cbias) return fail(RBD_ERR_ARG, "rbd_minv (forward dynamics): this robot's kernels need the bias force c");
   hipStream_t s = (hipStream_t)stream;
   const int pa = rbd_option(RBD_OPT_MINV_PHASE_A);
   // phase A: one lane per configuration when that alone fills the chip (>= 4 waves per SIMD),
@@ -2880,13 +2884,18 @@ int fd_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* qdd,
     if (e != hipSuccess) return hip_fail(e, "rbd_forward_dynamics_grad (gradient kernel) launch");
     return 0;
   } else {
-  // c = rnea(q, qd) with qdd = None (:1372), c-only kernel of the RNEA unit
-  if constexpr (sizeof(T) == 4) rc = rbd_rnea_f32((const float*)q, (const float*)qd, nullptr, (float)gravity, B, (float*)c, nullptr, nullptr, nullptr, stream);
-  else rc = rbd_rnea_f64((const double*)q, (const double*)qd, nullptr, (double)gravity, B, (double*)c, nullptr, nullptr, nullptr, stream);
-  if (rc != 0) return rc;
+  // c = rnea(q, qd) with qdd = None (:1372): the c-only kernel of the RNEA unit -- or, where the one-lane minv kernel serves the
+  // robot, no launch at all: that kernel computes the bias force of its groups from qd itself (rbd_minv_lane.h)
+  constexpr bool bias_in_minv = minv_use_lane<T>();
+  if constexpr (!bias_in_minv) {
+    if constexpr (sizeof(T) == 4) rc = rbd_rnea_f32((const float*)q, (const float*)qd, nullptr, (float)gravity, B, (float*)c, nullptr, nullptr, nullptr, stream);
+    else rc = rbd_rnea_f64((const double*)q, (const double*)qd, nullptr, (double)gravity, B, (double*)c, nullptr, nullptr, nullptr, stream);
+    if (rc != 0) return rc;
+  }
+  const T* cb = bias_in_minv ? nullptr : c;
   // qdd = Minv (u - c) (:1373-1374), fused into the last phase of minv (MINV unit)
-  if constexpr (sizeof(T) == 4) rc = rbd_minv_fd_f32((const float*)q, B, (float*)Mi, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T), stream, (const float*)u, (const float*)c, (float*)qdd_buf);
-  else rc = rbd_minv_fd_f64((const double*)q, B, (double*)Mi, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T), stream, (const double*)u, (const double*)c, (double*)qdd_buf);
+  if constexpr (sizeof(T) == 4) rc = rbd_minv_fd_f32((const float*)q, B, (float*)Mi, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T), stream, (const float*)u, (const float*)cb, (float*)qdd_buf, (const float*)qd, (float)gravity);
+  else rc = rbd_minv_fd_f64((const double*)q, B, (double*)Mi, w + L.off_minv_ws, (size_t)B * MINV_WS_PER_CFG * sizeof(T), stream, (const double*)u, (const double*)cb, (double*)qdd_buf, (const double*)qd, (double)gravity);
   if (rc != 0) return rc;
   if (!want_grad) return 0;
   // [qdd_dq | qdd_dqd] = -Minv rnea_grad(q, qd, qdd) (:1378-1383)
@@ -3152,8 +3161,8 @@ int rbd_minv_f32(const float* q, int64_t B, int output_dense, float* Minv, void*
   RbdStreamDevice sd_(stream); return minv_launch<float>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
 }
 int rbd_minv_fd_f32(const float* q, int64_t B, float* Minv, void* workspace, size_t wsb, void* stream,
-                    const float* u, const float* c, float* qdd) {
-  RbdStreamDevice sd_(stream); return minv_launch<float>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
+                    const float* u, const float* c, float* qdd, const float* qd, float gravity) {
+  RbdStreamDevice sd_(stream); return minv_launch<float>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd, qd, gravity);
 }
 #endif
 #ifdef RBD_TU_FD_F32
@@ -3188,8 +3197,8 @@ int rbd_minv_f64(const double* q, int64_t B, int output_dense, double* Minv, voi
   RbdStreamDevice sd_(stream); return minv_launch<double>(q, B, output_dense, Minv, workspace, workspace_bytes, stream);
 }
 int rbd_minv_fd_f64(const double* q, int64_t B, double* Minv, void* workspace, size_t wsb, void* stream,
-                    const double* u, const double* c, double* qdd) {
-  RbdStreamDevice sd_(stream); return minv_launch<double>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd);
+                    const double* u, const double* c, double* qdd, const double* qd, double gravity) {
+  RbdStreamDevice sd_(stream); return minv_launch<double>(q, B, 1, Minv, workspace, wsb, stream, u, c, qdd, qd, gravity);
 }
 #endif
 
@@ -3259,7 +3268,7 @@ int rbd_minv_fpass_f64(const double* q, int64_t B, double* Minv, double* F, cons
   int rbd_minv_needs_ws_##SFX(void) { return 1; }                                                                                \
   int rbd_crba_##SFX(const T*, int64_t, T*, void*) RBD_STUB_BODY("rbd_crba")                                                     \
   int rbd_minv_##SFX(const T*, int64_t, int, T*, void*, size_t, void*) RBD_STUB_BODY("rbd_minv")                                 \
-  int rbd_minv_fd_##SFX(const T*, int64_t, T*, void*, size_t, void*, const T*, const T*, T*) RBD_STUB_BODY("rbd_minv")
+  int rbd_minv_fd_##SFX(const T*, int64_t, T*, void*, size_t, void*, const T*, const T*, T*, const T*, T) RBD_STUB_BODY("rbd_minv")
 #define RBD_STUBS_FD(SFX, T)                                                                                                     \
   int rbd_aba_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*) RBD_STUB_BODY("rbd_aba")                                \
   int rbd_forward_dynamics_##SFX(const T*, const T*, const T*, T, int64_t, T*, void*, size_t, void*) RBD_STUB_BODY("rbd_forward_dynamics") \

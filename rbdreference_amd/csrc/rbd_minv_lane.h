@@ -36,7 +36,8 @@ constexpr int MINV_LANE_TS = (grad_max_rows() * N) | 1;
 template <class T>
 __global__ __launch_bounds__(64, (sizeof(T) == 4 && grad_max_rows() <= 8) ? 2 : 1) void minv_lane_kernel(const T* __restrict__ q, long long B, int dense,
                                                                               T* __restrict__ Minv, const T* __restrict__ u_in,
-                                                                              const T* __restrict__ c_in, T* __restrict__ qdd_out) {
+                                                                              const T* __restrict__ c_in, T* __restrict__ qdd_out,
+                                                                              const T* __restrict__ qd_in = nullptr, T grav = T(0)) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
   const int lane = threadIdx.x;
@@ -50,8 +51,16 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && grad_max_rows() <= 8) ? 2 : 
   T qv[N];
   sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; qv[j] = q[b * N + j]; });
   T tau[N], qacc[N];
+  // forward dynamics (:1371-1374): tau = u - c.  With qd_in the bias force c = rnea(q, qd, qdd = None) (:559-621) is computed
+  // HERE, group by group, from the sin / cos this lane holds anyway -- the separate c-only rnea launch and its [B, n] round
+  // trip are gone (the quadruped's forward_dynamics_grad in fp64, B = 65 536: 11 of 88 us)
+  const bool own_bias = fd && qd_in != nullptr;                  // (uniform over the launch)
   if (fd) {
-    sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tau[j] = u_in[b * N + j] - c_in[b * N + j]; qacc[j] = T(0); });
+    sfor<0, N>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      tau[j] = own_bias ? u_in[b * N + j] : u_in[b * N + j] - c_in[b * N + j];
+      qacc[j] = T(0);
+    });
   } else {
     sfor<0, N>([&](auto J) { constexpr int j = decltype(J)::value; tau[j] = T(0); qacc[j] = T(0); });
   }
@@ -64,6 +73,28 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && grad_max_rows() <= 8) ? 2 : 
     constexpr int row0 = grp_row0(rt);
     constexpr int rows = grp_rows(rt);
     T* my = tile + lane * MINV_LANE_TS - row0 * N;     // my[i * N + c], rows of this group
+    if (own_bias) {
+      T f[N][6], vb[N][6], ab[N][6];
+      sfor<row0, row0 + rows>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int p = PARENT[j];
+        T xv[6], xa[6];
+        const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        const T qdj = qd_in[b * N + j];
+        if constexpr (p < 0) rnea_fwd_body<j, false>(tr[j], qdj, T(0), grav, zero6, zero6, xv, xa, vb[j], ab[j], f[j]);
+        else rnea_fwd_body<j, false>(tr[j], qdj, T(0), grav, vb[p], ab[p], xv, xa, vb[j], ab[j], f[j]);
+      });
+      sfor_down<row0, row0 + rows>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int p = PARENT[j];
+        tau[j] -= S_dot<j>(f[j]);                                                   // c_j = S^T f_j (:612)
+        if constexpr (p >= 0) {
+          T y[6];
+          xform_T<j>(tr[j], f[j], y);                                               // f_p += X^T f_j (:618-619)
+          sfor<0, 6>([&](auto R) { f[p][decltype(R)::value] += y[decltype(R)::value]; });
+        }
+      });
+    }
     // ---- articulated inertias of the group (:662, :697-700, :728-733); IA is symmetric: 21 scalars per body, the lower half
     //      of X^T Ia X is never formed ------------------------------------------------------------------------------------
     {
