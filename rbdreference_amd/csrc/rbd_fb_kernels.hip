@@ -137,7 +137,7 @@ int grad_fb_launch(const char* who, const T* q, const T* qd, const T* qdd, T gra
 }
 template <class T>
 int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream, const T* u = nullptr, const T* cbias = nullptr, T* qdd = nullptr,
-                   bool* fused_qdd = nullptr) {
+                   bool* fused_qdd = nullptr, const T* qd = nullptr, T gravity = T(0)) {
   using namespace rbdk;
   if (fused_qdd) *fused_qdd = false;
   if (B < 0) return fail(RBD_ERR_ARG, "rbd_minv: B < 0");
@@ -154,7 +154,9 @@ int minv_fb_launch(const T* q, int64_t B, int dense, T* Minv, void* stream, cons
       int rcm;
       if ((rcm = ensure_lds(km, ldsm)) != 0) return rcm;
       // with u, c, qdd: qdd = Minv (u - c) leaves the same launch (rbd_fb_minv.h); Minv may then be null
-      hipLaunchKernelGGL(km, dim3((unsigned)nb), dim3(64 * FBW_W), ldsm, (hipStream_t)stream, q, (long long)B, dense, Minv, u, cbias, qdd);
+      // (qd instead of c: the kernel computes the bias force itself)
+      hipLaunchKernelGGL(km, dim3((unsigned)nb), dim3(64 * FBW_W), ldsm, (hipStream_t)stream, q, (long long)B, dense, Minv, u, cbias, qdd,
+                         cbias ? (const T*)nullptr : qd, gravity);
       if (fused_qdd) *fused_qdd = qdd != nullptr;
       hipError_t em = hipGetLastError();
       return em == hipSuccess ? 0 : hip_fail(em, "rbd_minv (floating base, wave per subtree) launch");
@@ -186,12 +188,21 @@ int fd_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* q
   T* c = reinterpret_cast<T*>(w + off_c);
   T* Mi = reinterpret_cast<T*>(w + off_m);
   int rc;
-  if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
-  // :1373-1374 in one launch where the wave-per-subtree kernel serves the robot: qdd = Minv (u - c) from the columns in
-  // registers, the matrix itself is never written (Minv = nullptr); else minv into the workspace + the product kernel
+  // :1372-1374 in ONE launch where the wave-per-subtree kernel serves the robot: the bias force from qd, qdd = Minv (u - c) from
+  // the columns in registers, the matrix itself never written (Minv = nullptr); else rnea, minv into the workspace and
+  // the product kernel
   bool fused = false;
+#ifdef RBD_FB_EXP_NO_OWN_BIAS      // timing experiment: the c-only rnea launch as before
+  const bool wave_kernel = false;
+#else
   const bool wave_kernel = minv_fbm_ok<T>() && rbd_option(RBD_OPT_MINV_PHASE_A) != RBD_MINV_PHASE_A_LANE;
-  if ((rc = minv_fb_launch<T>(q, B, 1, wave_kernel ? (T*)nullptr : Mi, stream, u, (const T*)c, qdd, &fused)) != 0) return rc;
+#endif
+  if (wave_kernel) {
+    if ((rc = minv_fb_launch<T>(q, B, 1, (T*)nullptr, stream, u, (const T*)nullptr, qdd, &fused, qd, gravity)) != 0) return rc;
+    if (fused) return 0;
+  }
+  if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
+  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream, u, (const T*)c, qdd, &fused)) != 0) return rc;
   if (fused) return 0;
   const int64_t ab = ((int64_t)B * NV + 255) / 256;
   if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics: B too large");
@@ -320,9 +331,19 @@ int fdg_fb_launch(const T* q, const T* qd, const T* u, T gravity, int64_t B, T* 
   T* dc = reinterpret_cast<T*>(w + o);
   T* qdd = qdd_out ? qdd_out : qdd_ws;
   int rc;
-  if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
   bool fused = false;
-  if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream, u, (const T*)c, qdd, &fused)) != 0) return rc;                   // :1373, :1381 (+ :1374 where fused)
+#ifdef RBD_FB_EXP_NO_OWN_BIAS
+  const bool wave_kernel = false;
+#else
+  const bool wave_kernel = minv_fbm_ok<T>() && rbd_option(RBD_OPT_MINV_PHASE_A) != RBD_MINV_PHASE_A_LANE;
+#endif
+  if (wave_kernel) {   // :1372-1374 and :1381 in one launch (bias force from qd inside the minv kernel)
+    if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream, u, (const T*)nullptr, qdd, &fused, qd, gravity)) != 0) return rc;
+    if (!fused) return fail(RBD_ERR_UNSUPPORTED, "rbd_forward_dynamics_grad: the wave-per-subtree minv kernel did not run");
+  } else {
+    if ((rc = rnea_fb_launch<T>(q, qd, nullptr, gravity, B, c, nullptr, nullptr, nullptr, stream)) != 0) return rc;   // :1372
+    if ((rc = minv_fb_launch<T>(q, B, 1, Mi, stream, u, (const T*)c, qdd, &fused)) != 0) return rc;                   // :1373, :1381 (+ :1374 where fused)
+  }
   if (!fused) {
     const int64_t ab = ((int64_t)B * NV + 255) / 256;
     if (ab > 0x7fffffffLL) return fail(RBD_ERR_ARG, "rbd_forward_dynamics_grad: B too large");

@@ -31,6 +31,10 @@ constexpr int FBM_IA0 = 21;                                 // symmetric 6 x 6 c
 constexpr int FBM_Q = 16;                                   // configurations per output image
 constexpr int FBM_IMG = FBM_Q * NV * NV;                    // scalars of the image
 constexpr int FBM_PRIV = FBM_REC * N + FBM_IA0 * FBW_W;     // lane-private scalars (slot * 64 + lane)
+// forward dynamics with the bias force computed here: f_0 contributions [W][6] and c of the joints [NV], lane-private, in the
+// IMAGE's space (the image is first written after the column phase; a block's LDS stays at two blocks per CU)
+constexpr int FBM_BIAS_SLOTS = 6 * FBW_W + NV;
+static_assert(64 * FBM_BIAS_SLOTS <= FBM_IMG, "bias-force slots live in the output image's space");
 template <class T>
 constexpr size_t minv_fbm_lds_bytes() { return sizeof(T) * ((size_t)FBM_IMG + (size_t)64 * FBM_PRIV); }
 template <class T>
@@ -52,7 +56,7 @@ constexpr int fbm_sym_index(int r, int c) {                 // r <= c -> 0..20
 template <class T>
 __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __restrict__ q, long long B, int dense, T* __restrict__ Minv,
                                                                   const T* __restrict__ u_in = nullptr, const T* __restrict__ c_in = nullptr,
-                                                                  T* __restrict__ qdd_out = nullptr) {
+                                                                  T* __restrict__ qdd_out = nullptr, const T* __restrict__ qd_in = nullptr, T grav = T(0)) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* img = reinterpret_cast<T*>(smem_raw);                                   // [FBM_Q][NV * NV]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,6 +69,28 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __rest
   auto rec = [&](int i, int k) -> T& { return priv[(FBM_REC * i + k) * 64]; };
   auto ia0 = [&](int w, int k) -> T& { return priv[(FBM_REC * N + FBM_IA0 * w + k) * 64]; };
 
+  // forward dynamics with qd instead of c: the bias force c = rnea(q, qd, qdd = None) (:559-621 with the floating-base lines
+  // :585, :591, :612) is computed here, subtree by subtree next to the articulated inertias -- every wave the base's v_0, a_0
+  // (cheap), its own bodies' v, a, f and joint entries c_j, and what its subtrees hand to f_0; the pieces meet in lane-private
+  // LDS slots at the barrier phase B waits at anyway.  (The c-only rnea launch this replaces: 10 of forward_dynamics' 28 us.)
+  const bool own_bias = qdd_out != nullptr && qd_in != nullptr;  // (uniform over the launch)
+  auto f0s = [&](int w, int r) -> T& { return img[(6 * w + r) * 64 + lane]; };
+  auto cjs = [&](int j) -> T& { return img[(6 * FBW_W + j) * 64 + lane]; };
+  const T* qdb = own_bias ? qd_in + b * NV : q;                  // (never read without own_bias)
+  T v0[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, a0[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, f0acc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  if (own_bias) {
+    T E[3][3];
+    fb_base_E(qb[3], qb[4], qb[5], E);
+    sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; v0[r] = qdb[r]; });
+    a0[3] = -(grav * E[0][2]); a0[4] = -(grav * E[1][2]); a0[5] = -(grav * E[2][2]);   // X_0 a_grav (rbd_fb.h: rnea_fb_kernel)
+    if (wave == 0) {                                             // the base's own force, once
+      T Iv[6], Ia[6];
+      cmatvec<MatI, 0>(v0, Iv);
+      cmatvec<MatI, 0>(a0, Ia);
+      sfor<0, 6>([&](auto R) { f0acc[decltype(R)::value] = Ia[decltype(R)::value]; });
+      fxv<true>(v0, Iv, f0acc);
+    }
+  }
   // ---- phase A: this wave's subtrees ---------------------------------------------------------------------------
   {
     T acc0[6][6];                                             // what this wave's subtrees hand to the base
@@ -83,6 +109,28 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __rest
               sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; IA[j][r][c] = T(IM[j][r * 6 + c]); }); });
             }
           });
+          if (own_bias) {
+            T vb[N][6], ab[N][6], fbd[N][6];
+            sfor<1, N>([&](auto J) {
+              constexpr int j = decltype(J)::value;
+              if constexpr (fbw_child_root(j) == rt) {
+                constexpr int p = PARENT[j];
+                T xv[6], xa[6];
+                if constexpr (p == 0) rnea_fwd_body<j, false>(tr[j], qdb[j + 5], T(0), grav, v0, a0, xv, xa, vb[j], ab[j], fbd[j]);
+                else rnea_fwd_body<j, false>(tr[j], qdb[j + 5], T(0), grav, vb[p], ab[p], xv, xa, vb[j], ab[j], fbd[j]);
+              }
+            });
+            sfor_down<1, N>([&](auto J) {
+              constexpr int j = decltype(J)::value;
+              if constexpr (fbw_child_root(j) == rt) {
+                constexpr int p = PARENT[j];
+                cjs(j + 5) = S_dot<j>(fbd[j]);                                          // :612
+                T t[6];
+                xform_T<j>(tr[j], fbd[j], t);                                            // :618-619
+                sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; if constexpr (p == 0) f0acc[r] += t[r]; else fbd[p][r] += t[r]; });
+              }
+            });
+          }
           sfor_down<1, N>([&](auto I) {
             constexpr int i = decltype(I)::value;
             if constexpr (fbw_child_root(i) == rt) {
@@ -117,6 +165,7 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __rest
       }
     });
     sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; if constexpr (c >= r) ia0(wave, fbm_sym_index(r, c)) = acc0[r][c]; }); });
+    if (own_bias) { sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; f0s(wave, r) = f0acc[r]; }); }
   }
   __syncthreads();
   // ---- phase B: the base block (every wave, redundantly) -----------------------------------------------------------
@@ -141,7 +190,18 @@ __global__ __launch_bounds__(64 * FBW_W, 1) void minv_fbm_kernel(const T* __rest
   T colv[fbm_max_cols()][NV];
   const bool fd = qdd_out != nullptr;                            // (uniform over the launch)
   T tau[NV], qacc[NV];
-  sfor<0, NV>([&](auto R) { constexpr int r = decltype(R)::value; tau[r] = fd ? u_in[b * NV + r] - c_in[b * NV + r] : T(0); qacc[r] = T(0); });
+  sfor<0, NV>([&](auto R) {
+    constexpr int r = decltype(R)::value;
+    T cr = T(0);
+    if (own_bias) {
+      if constexpr (r < 6) { sfor<0, FBW_W>([&](auto W_) { cr += f0s(decltype(W_)::value, r); }); }      // c[0:6] = f_0 (S = eye(6), :612)
+      else cr = cjs(r);
+    } else if (fd) {
+      cr = c_in[b * NV + r];
+    }
+    tau[r] = fd ? u_in[b * NV + r] - cr : T(0);
+    qacc[r] = T(0);
+  });
   if (fd && wave == 0) {                                         // the base block times tau[0:6]
     sfor<0, 6>([&](auto R) { sfor<0, 6>([&](auto C) { constexpr int r = decltype(R)::value, c = decltype(C)::value; qacc[r] = fma_(fb6[r][c], tau[c], qacc[r]); }); });
   }
