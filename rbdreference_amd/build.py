@@ -359,7 +359,8 @@ GENERIC_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-share
 
 
 def generic_lib_path() -> str:
-    return os.path.join(BUILD_DIR, "librbd_generic.so")
+    # (RBD_GENERIC_LIB: a variant build for timing experiments, tools/time_generic.py)
+    return os.environ.get("RBD_GENERIC_LIB") or os.path.join(BUILD_DIR, "librbd_generic.so")
 
 
 def _generic_digest() -> str:

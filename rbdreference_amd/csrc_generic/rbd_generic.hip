@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -23,8 +24,21 @@
 #include "../csrc/rbd_sincos.h"
 
 #define GDEV __device__ __forceinline__
+#ifndef RBD_G_EXTRA_LDS_DEFAULT
+#define RBD_G_EXTRA_LDS_DEFAULT 0
+#endif
 
 namespace rbdg {
+
+// Resident waves per CU of the lane-per-configuration kernels.  Their per-lane state lives in private (scratch) memory, 1.4-37 KB
+// per lane, and a launch's scratch footprint is (resident waves) x 64 x that: with every wave slot the LDS tile allows (9 per
+// CU) the 7-body gradient kernel's footprint is 426 MB -- more than the 256 MB last-level cache, so every private access is an
+// HBM access.  Extra dynamic LDS per block caps the residency (RBD_G_EXTRA_LDS bytes; default chosen from measurements).
+inline size_t extra_lds() {
+  static const size_t v = [] { const char* e = std::getenv("RBD_G_EXTRA_LDS"); return e ? (size_t)std::atol(e) : (size_t)RBD_G_EXTRA_LDS_DEFAULT; }();
+  return v;
+}
+
 
 constexpr int MB = RBD_G_MAX_BODIES;
 
@@ -166,7 +180,10 @@ GDEV void base_X(const T (&bt)[9], T (&X)[36]) {
 // are 4-byte stores 2 n^2 (or 6 n, n^2) elements apart between neighbouring lanes -- every 64-byte sector is written
 // sixteen times, partially.  Instead the values collect in a private array and leave KCH per configuration at a time:
 // tile[lane][k] <- private, then consecutive lanes store consecutive elements of one configuration (256-byte runs).
-constexpr int KCH = 64;
+#ifndef RBD_G_KCH
+#define RBD_G_KCH 64
+#endif
+constexpr int KCH = RBD_G_KCH;
 constexpr int KCHP = KCH + 1;                       // odd row stride: the lane-major tile writes hit 64 different banks
 template <int NMAX>
 constexpr bool stage_outputs() { return NMAX <= 32; }   // (64 bodies: 2 * 69^2 values per lane would not fit private memory)
@@ -1381,7 +1398,7 @@ int rnea_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav,
   if (!q || !qd || !c) return fail(RBD_G_ERR_ARG, "rbd_g_rnea: q, qd, c must not be null");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f, stage_for(B))
+#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_kernel<T, NM, FB>), dim3(grid), dim3(64), extra_lds(), (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, B, c, v, a, f, stage_for(B))
   RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
@@ -1398,14 +1415,14 @@ int grad_host(const rbd_model* m, const T* q, const T* qd, const T* qdd, T grav,
   const int opt = g_grad_kernel_option.load(std::memory_order_relaxed);
   if (m->world_ok && opt != RBD_G_GRAD_KERNEL_COLUMNS) {
     const int n_ = m->n;
-#define WCALL(NM) hipLaunchKernelGGL((g_rnea_grad_world_kernel<T, NM>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc, stage_for(B))
+#define WCALL(NM) hipLaunchKernelGGL((g_rnea_grad_world_kernel<T, NM>), dim3(grid), dim3(64), extra_lds(), (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc, stage_for(B))
     if (n_ <= 8) { WCALL(8); } else if (n_ <= 16) { WCALL(16); } else if (n_ <= 32) { WCALL(32); } else { WCALL(64); }
 #undef WCALL
     hipError_t ew = hipGetLastError();
     return ew == hipSuccess ? 0 : hip_fail(ew, "rbd_g_rnea_grad (world-frame kernel) launch");
   }
   if (opt == RBD_G_GRAD_KERNEL_WORLD) return fail(RBD_G_ERR_UNSUPPORTED, "rbd_g_rnea_grad: the world-frame kernel needs a fixed base, revolute joints and rigid-body inertias");
-#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc, stage_for(B))
+#define CALL(NM, FB) hipLaunchKernelGGL((g_rnea_grad_kernel<T, NM, FB>), dim3(grid), dim3(64), extra_lds(), (hipStream_t)stream, dev_of<T>(m), q, qd, qdd, grav, damp, B, c, dc, stage_for(B))
   RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
@@ -1417,7 +1434,7 @@ int minv_host(const rbd_model* m, const T* q, long long B, int dense, T* Minv, v
   if (!q || !Minv) return fail(RBD_G_ERR_ARG, "rbd_g_minv: q, Minv must not be null");
   if (B == 0) return 0;
   const unsigned grid = (unsigned)((B + 63) / 64);
-#define CALL(NM, FB) hipLaunchKernelGGL((g_minv_kernel<T, NM, FB>), dim3(grid), dim3(64), 0, (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv, stage_for(B))
+#define CALL(NM, FB) hipLaunchKernelGGL((g_minv_kernel<T, NM, FB>), dim3(grid), dim3(64), extra_lds(), (hipStream_t)stream, dev_of<T>(m), q, B, dense, Minv, stage_for(B))
   RBDG_DISPATCH(m, CALL);
 #undef CALL
   hipError_t e = hipGetLastError();
