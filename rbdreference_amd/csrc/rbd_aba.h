@@ -126,12 +126,12 @@ RBD_DEV void aba_group(T grav, Ctx& st) {
       T U[6], pA[6], ci[6];
       sfor<0, 6>([&](auto R) {
         constexpr int r = decltype(R)::value;
-        U[r] = IA[i][r][si];
+        U[r] = IA[i][r <= si ? r : si][r <= si ? si : r];          // (IA is symmetric: only its upper triangle is kept up to date)
         pA[r] = st.template get<i * ABA_SLOTS + 4 + r>();
         if constexpr (c_nonzero(i, r)) ci[r] = st.template get<i * ABA_SLOTS + c_slot(i, r)>();
         else ci[r] = T(0);
       });
-      const T dinv = T(1) / U[si];
+      const T dinv = rcp_inertia(U[si]);
       const T u = st.template tau<i>() - pA[si];                    // (:992)
       if constexpr (p >= 0) {
         const JTrig<T> g = st.template trig<i>();
@@ -143,7 +143,7 @@ RBD_DEV void aba_group(T grav, Ctx& st) {
           T acc = fma_(U[r], k, pA[r]);
           sfor<0, 6>([&](auto C) {
             constexpr int c = decltype(C)::value;
-            if constexpr (c_nonzero(i, c)) acc = fma_(IA[i][r][c], ci[c], acc);
+            if constexpr (c_nonzero(i, c)) acc = fma_(IA[i][r <= c ? r : c][r <= c ? c : r], ci[c], acc);
           });
           pa[r] = acc;
         });
@@ -159,7 +159,7 @@ RBD_DEV void aba_group(T grav, Ctx& st) {
           constexpr int c = decltype(C)::value;
           T col[6], yc[6];
           const T uc = U[c] * dinv;
-          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[r], uc, IA[i][r][c]); });
+          sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; col[r] = fma_(-U[r], uc, IA[i][r <= c ? r : c][r <= c ? c : r]); });
           xform_T<i>(g, col, yc);
           sfor<0, 6>([&](auto R) { A[decltype(R)::value][c] = yc[decltype(R)::value]; });
         });
@@ -167,7 +167,7 @@ RBD_DEV void aba_group(T grav, Ctx& st) {
           constexpr int r = decltype(R)::value;
           T yr[6];
           xform_T<i>(g, A[r], yr);
-          sfor<0, 6>([&](auto C) { IA[p][r][decltype(C)::value] += yr[decltype(C)::value]; });
+          sfor<r, 6>([&](auto C) { IA[p][r][decltype(C)::value] += yr[decltype(C)::value]; });   // upper triangle of the symmetric X^T Ia X
         });
       }
       // hand U, 1/d, u to sweep 3 (U takes over pA's slots)
