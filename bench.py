@@ -145,9 +145,17 @@ def time_kernel_ms(fn, steps, warmup):
     return e0.elapsed_time(e1) / steps
 
 
-def time_extra_ms(fn, steps, warmup, reps=3):
+def time_extra_ms(fn, steps, warmup, reps=3, ramp_s=0.05):
     """Extras only: best of `reps` timed groups (one stalled launch on a shared box otherwise
-    dominates a 20-launch average)."""
+    dominates a 20-launch average).  Like the headline (main(): "clock ramp"), every extra is timed at the GPU's
+    working clock: its set-up (allocations, a library load) leaves the GPU idle for milliseconds, and a group of a hundred
+    20 us launches is over before the clock is back -- the 30-body minv measured 22.9 us this way against 20.4 us in
+    a loop that runs for seconds (tools/exp_minv_abi.py).  `ramp_s` seconds of the same launches, untimed, come first."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp_s:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     return min(time_kernel_ms(fn, steps, warmup if r == 0 else 1) for r in range(reps))
 
 
