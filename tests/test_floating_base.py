@@ -366,3 +366,37 @@ def test_fb_both_minv_kernels_vs_golden(name):
                 assert e <= tol, (want, dt, "ragged", e)
     finally:
         rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, RBD_MINV_PHASE_A_AUTO)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", fb_golden_names())
+def test_fb_forward_dynamics_one_launch_and_three_launch_paths(name):
+    """forward_dynamics(_grad) of a floating-base robot on both paths: AUTO = ONE launch (the wave-per-subtree minv kernel
+    computes the bias force from qd and qdd = Minv (u - c) itself, rbd_fb_minv.h) and RBD_MINV_PHASE_A_LANE = the c-only rnea
+    launch + the four-lanes minv + the product kernel; both against the oracle (RBDReference.py:1371-1384), both precisions, a
+    ragged batch, non-default gravity."""
+    import torch
+    from rbdreference_amd._lib import RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE, RBD_OPT_MINV_PHASE_A
+    rbd = _rbd(name); m = fbo.model_from_robot(make_robot(name))
+    rng = np.random.default_rng(11)
+    B = 83
+    q, qd, u = rng.uniform(-np.pi, np.pi, (B, m.n)), rng.uniform(-1, 1, (B, m.n)), rng.uniform(-2, 2, (B, m.n))
+    for grav in (-9.81, -3.7):
+        qdd_ref = fbo.forward_dynamics(m, q, qd, u, grav)
+        has_grad = m.nb >= 6                    # (the reference's floating-base rnea_grad needs NB >= 6, :1168)
+        if has_grad:
+            dq_ref, dqd_ref = fbo.forward_dynamics_grad(m, q, qd, u, grav)
+        try:
+            for opt in (RBD_MINV_PHASE_A_AUTO, RBD_MINV_PHASE_A_LANE):
+                rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, opt)
+                for dt, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+                    tq, tqd, tu = (torch.tensor(x, device="cuda:0", dtype=dt) for x in (q, qd, u))
+                    qdd = rbd.forward_dynamics(tq, tqd, tu, GRAVITY=grav)
+                    assert rel_err_rows(qdd.double().cpu().numpy(), qdd_ref) <= tol, (opt, dt, grav)
+                    if not has_grad:
+                        continue
+                    dq, dqd = rbd.forward_dynamics_grad(tq, tqd, tu, GRAVITY=grav)
+                    assert rel_err_rows(dq.double().cpu().numpy(), dq_ref) <= tol * 10, (opt, dt, grav)
+                    assert rel_err_rows(dqd.double().cpu().numpy(), dqd_ref) <= tol * 10, (opt, dt, grav)
+        finally:
+            rbd._lib.set_option(RBD_OPT_MINV_PHASE_A, RBD_MINV_PHASE_A_AUTO)
