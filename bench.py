@@ -225,18 +225,62 @@ def sources_digest():
     return h.hexdigest()[:16]
 
 
-def timed_steps(step, steps, warmup, dist, dev, graph=False):
+def pick_graph(step, steps, dist, dev):
+    """--graph auto, strong scaling on several GPUs: an UNTIMED calibration decides how the K timed launches are issued.
+    The same K launches, eager and as one replay of a HIP graph, are timed once each (after a replay for the graph's
+    upload and 0.2 s of replays: both candidates at the working clock, interleaved, best of three); the graph is used when
+    it is at least 3 % faster on the slowest rank.  Why not always: measured this way the two are within 1-2 % of each other
+    at every shard size on most boxes (19.8 vs 20.1 us per launch at 131 072 rows, 37.3 vs 37.1 at 262 144, 69.3 vs 68.3 at
+    524 288), on one box of this round the replay was 18.7 against 20.5 us at 131 072 -- so the choice is measured on the box
+    that runs.  (A replay timed right after the capture, with the GPU back at its idle clock, reads 10-25 % slow: the first
+    version of this bench did that.)  Returns (use_graph, GraphSteps or None, the two times).""" 
+    n = max(5, min(steps, 20))
+    gs = GraphSteps(step, steps, dev)
+
+    def spin(fn, seconds):                   # both candidates are timed at the working clock (the capture left the GPU idle)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            torch.cuda.synchronize()
+
+    def timed(fn, per):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / per
+
+    def eager_n():
+        for _ in range(n):
+            step()
+    spin(gs, 0.2)
+    t_eager, t_graph = 1e30, 1e30
+    for _ in range(3):                       # interleaved, best of three each
+        t_graph = min(t_graph, timed(gs, steps))
+        t_eager = min(t_eager, timed(eager_n, n))
+    if dist is not None:
+        t = torch.tensor([t_eager, t_graph], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_eager, t_graph = t[0].item(), t[1].item()
+    use = t_graph < 0.97 * t_eager
+    return use, (gs if use else None), {"eager_ms_per_launch": t_eager, "graph_ms_per_launch": t_graph}
+
+
+def timed_steps(step, steps, warmup, dist, dev, graph=False, prebuilt=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.
     Returns (wall seconds, HIP-event ms per step on the launch stream): this rank's.
     graph: the K steps are captured (untimed) into one HIP graph and the timed region is its replay -- the same K launches."""
     run = None
     if graph:
-        gs = GraphSteps(step, steps, dev)
+        gs = prebuilt if prebuilt is not None else GraphSteps(step, steps, dev)
         run = gs
     for _ in range(warmup):
         step()
     if run is not None:
         run()                                    # one untimed replay (graph upload)
+        torch.cuda.synchronize()
+        t_spin = time.perf_counter()             # capture + instantiation left the GPU idle: untimed replays back to the working clock
+        while time.perf_counter() - t_spin < 0.2:
+            run()
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -315,20 +359,28 @@ def main():
     if dist is not None:
         dist.barrier()                       # builds the RCCL communicator (100s of ms): before the clock ramp
         torch.cuda.synchronize()
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.3:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1 and args.scaling == "strong")
-    wall, kern_ms = timed_steps(step, args.steps, args.warmup, dist, dev, graph=use_graph)
+    def ramp():
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.3:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+    ramp()
+    use_graph, prebuilt, graph_cal = args.graph == "on", None, None
+    if args.graph == "auto" and (world > 1 or os.environ.get("RBD_BENCH_CALIBRATE")) and args.scaling == "strong":   # (env: rehearse the calibration on one GPU)
+        use_graph, prebuilt, graph_cal = pick_graph(step, args.steps, dist, dev)
+        ramp()                               # (the capture and instantiation left the GPU idle: back to the working clock)
+    wall, kern_ms = timed_steps(step, args.steps, args.warmup, dist, dev, graph=use_graph, prebuilt=prebuilt)
 
     other = None
     if world > 1:                            # the other scaling mode, same run, reported beside the headline
         omode = "weak" if args.scaling == "strong" else "strong"
         ostep = make_step(omode)
         rbd._lib.set_option(RBD_OPT_SELECT_BATCH, B if omode == "strong" else 0)
-        ow, ok = timed_steps(ostep, args.steps, args.warmup, dist, dev, graph=(args.graph == "on" or (args.graph == "auto" and omode == "strong")))
+        og, opre = args.graph == "on", None
+        if args.graph == "auto" and omode == "strong":
+            og, opre, _ = pick_graph(ostep, args.steps, dist, dev)
+        ow, ok = timed_steps(ostep, args.steps, args.warmup, dist, dev, graph=og, prebuilt=opre)
         rbd._lib.set_option(RBD_OPT_SELECT_BATCH, 0)
         orows = B if omode == "strong" else world * B
         other = {"scaling": omode, "value": orows * args.steps / ow, "unit": "evals/s", "ms_per_step": ow / args.steps * 1e3,
@@ -390,6 +442,7 @@ def main():
                        "robot": "iiwa_like", "batch_per_gpu": rows_rank, "global_batch": rows_global,
                        "buffer_sets": nsets,
                        "launch": (f"one replay of a HIP graph of the {args.steps} launches" if use_graph else "eager launches"),
+                       "launch_calibration": graph_cal,
                        "parallelism": f"batch-shard x{world} (no data-path collective)"},
             "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
