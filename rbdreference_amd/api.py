@@ -258,6 +258,11 @@ class RBDReference:
             raise ValueError(f"out: `{name}` must be a contiguous {dt} tensor of shape {tuple(shape)} on {dev}")
         return t
 
+    @staticmethod
+    def _out_ok(t, shape, dt, idx):
+        """`out=` tensor usable by the cached launch plan as it is (else the general path checks it and says what is wrong)."""
+        return type(t) is _T and t.dtype is dt and t.get_device() == idx and tuple(t.shape) == shape and t.is_contiguous()
+
     def _fn(self, base: str, dt, has_qdd: bool = True):
         return self._lib.fn(base, "f32" if dt == torch.float32 else "f64", has_qdd)
 
@@ -279,6 +284,20 @@ class RBDReference:
                     if rc != 0:
                         self._lib.check(rc)
                     return o.outs
+        if out is not None and outputs == "cvaf" and len(out) == 4:
+            # pre-allocated outputs through the cached plan too: the call is the same single ctypes launch, without the pool
+            sg = self._sig(q, qd, qdd)
+            if sg is not None:
+                B, dt, idx, st = sg
+                vs = (B, 6, self.n)
+                if self._out_ok(out[0], (B, self.nv), dt, idx) and all(self._out_ok(t, vs, dt, idx) for t in out[1:]):
+                    p = self._plan(("rnea", B, dt, idx, st), lambda: self._mk_plan("rbd_rnea", dt, idx, ((B, self.nv), vs, vs, vs)))
+                    if p is not None:
+                        rc = p.fn(q.data_ptr(), qd.data_ptr(), None if qdd is None else qdd.data_ptr(), float(GRAVITY), B,
+                                  out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), st)
+                        if rc != 0:
+                            self._lib.check(rc)
+                        return out[0], out[1], out[2], out[3]
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         if out is not None:
@@ -508,6 +527,21 @@ class RBDReference:
                     if rc != 0:
                         self._lib.check(rc)
                     return o.outs if return_c else o.outs[0]
+        if out is not None:
+            sg = self._sig(q, qd, qdd)
+            if sg is not None:
+                B, dt, idx, st = sg
+                hq = qdd is not None
+                oc, odc = (out if (return_c and type(out) in (tuple, list) and len(out) == 2) else (None, out))
+                if self._out_ok(odc, (B, self.nv, 2 * self.nv), dt, idx) and (not return_c or self._out_ok(oc, (B, self.nv), dt, idx)):
+                    p = self._plan(("rnea_grad", B, dt, idx, st, hq, return_c),
+                                   lambda: self._mk_plan("rbd_rnea_grad", dt, idx, ((B, self.nv), (B, self.nv, 2 * self.nv)) if return_c else ((B, self.nv, 2 * self.nv),), hq))
+                    if p is not None:
+                        rc = p.fn(q.data_ptr(), qd.data_ptr(), qdd.data_ptr() if hq else None, float(GRAVITY), 1 if USE_VELOCITY_DAMPING else 0, B,
+                                  oc.data_ptr() if return_c else None, odc.data_ptr(), st)
+                        if rc != 0:
+                            self._lib.check(rc)
+                        return (oc, odc) if return_c else odc
         (q, qd, qdd), unb, is_np, dev, dt = self._prep(q, qd, qdd)
         B = q.shape[0]
         if out is not None:      # out=dc_du, or out=(c, dc_du) with return_c=True: pre-allocated device tensors
@@ -579,6 +613,18 @@ class RBDReference:
                     if rc != 0:
                         self._lib.check(rc)
                     return o.outs[0]
+        if out is not None and workspace is None:
+            sg = self._sig(q, None, None)
+            if sg is not None:
+                B, dt, idx, st = sg
+                if self._out_ok(out, (B, self.nv, self.nv), dt, idx):
+                    p = self._plan(("minv", B, dt, idx, st), lambda: self._mk_plan(
+                        "rbd_minv", dt, idx, ((B, self.nv, self.nv),), ws_query=lambda lib, esz: lib.rbd_minv_workspace_bytes(B, esz)))
+                    if p is not None:
+                        rc = p.fn(q.data_ptr(), B, 1 if output_dense else 0, out.data_ptr(), p.wsp if p.wsb else None, p.wsb, st)
+                        if rc != 0:
+                            self._lib.check(rc)
+                        return out
         (q,), unb, is_np, dev, dt = self._prep(q)
         B = q.shape[0]
         esz = 4 if dt == torch.float32 else 8
