@@ -84,8 +84,44 @@ constexpr int TREE_INCH_TOTAL = TREE_MULTI ? TP.inch_off[TP.n_waves] : max_chain
 constexpr int TREE_CROSS = TREE_INCH + TREE_INCH_TOTAL;
 constexpr int TREE_PARK = TREE_CROSS + 2 * n_cross_pairs();
 constexpr int TREE_PRIV = TREE_PARK + TREE_COMP * n_parked_chains();
+// ---- two rows at a time ------------------------------------------------------------------------------------------------------
+// A row of dc_du is 8n bytes (240 B at n = 30) at 16-byte alignment: written alone it touches 4-5 granules of 64 bytes (1.20 x
+// its bytes at the L2's memory side), and beyond the last-level cache the write path, not the arithmetic, sets the kernel's
+// time (every block writing ONE block's region: 97.6 instead of 185 us at B = 65 536).  Consecutive bodies of a chain
+// (j + 1, j with PARENT[j + 1] == j) own ADJACENT rows: the first waits in 2n registers (one wave per SIMD: 512 registers) and
+// the pair leaves as one 16n-byte piece per configuration, two configurations per store instruction, through a
+// [32][2 x 2n (+ pad)] image, 32 configurations at a time.
+#ifndef RBD_TREE_PAIR
+#define RBD_TREE_PAIR 0
+#endif
 template <class T>
-constexpr size_t tree_lds_bytes() { return sizeof(T) * (size_t)64 * (TREE_W * TREE_KP + TREE_PRIV); }
+constexpr bool tree_pair_ok() { return RBD_TREE_PAIR && sizeof(T) == 4 && (N % 2 == 0) && (TREE_KP % 4 == 0) && !RBD_TREE_NO_BUF_FLUSH && N <= 32; }
+constexpr int TREE_PKP = 4 * (N | 1);                         // scalars per configuration of the pair image: N 16-byte pieces + pad (odd count)
+template <class T>
+constexpr int tree_img_scalars() {                            // one wave's image
+  return tree_pair_ok<T>() && 32 * TREE_PKP > 64 * TREE_KP ? 32 * TREE_PKP : 64 * TREE_KP;
+}
+// role of body j's row: 1 = first of a pair (kept in registers), 2 = second (the pair leaves), 0 = alone
+constexpr int tree_pair_role(int j) {
+  const int h = chain_head_of(j);
+  int k = chain_leaf(h);
+  for (int guard = 0; guard < N + 1; ++guard) {
+    if (k == h) return 0;
+    const int p = PARENT[k];
+    if (p == k - 1 && in_chain(p, h)) {
+      if (j == k) return 1;
+      if (j == p) return 2;
+      if (p == h) return 0;
+      k = PARENT[p];
+    } else {
+      if (j == k) return 0;
+      k = p;
+    }
+  }
+  return 0;
+}
+template <class T>
+constexpr size_t tree_lds_bytes() { return sizeof(T) * ((size_t)TREE_W * tree_img_scalars<T>() + (size_t)64 * TREE_PRIV); }
 
 constexpr int tree_pend_slot(int jj, int j) {   // slot of the (dq, dqd) pair for row jj, column j
   if (chain_head_of(jj) == chain_head_of(j)) {
@@ -110,8 +146,8 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
                                                                long long B, T* __restrict__ c_out, T* __restrict__ dcdu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  T* rowimg = reinterpret_cast<T*>(smem_raw) + wave * (64 * TREE_KP);   // [64][TREE_KP], one image per wave
-  T* priv = reinterpret_cast<T*>(smem_raw) + TREE_W * 64 * TREE_KP + lane;   // priv[slot * 64], shared by the waves (same lane = same configuration)
+  T* rowimg = reinterpret_cast<T*>(smem_raw) + wave * tree_img_scalars<T>();   // [64][TREE_KP] (or the pair image [32][TREE_PKP]), one per wave
+  T* priv = reinterpret_cast<T*>(smem_raw) + TREE_W * tree_img_scalars<T>() + lane;   // priv[slot * 64], shared by the waves (same lane = same configuration)
   const long long cfg0 = (long long)blockIdx.x * 64;
   const long long rem = B - cfg0;
   const int nvalid = rem < 64 ? (int)rem : 64;
@@ -161,6 +197,8 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
       });
       // ---- leaf -> head ---------------------------------------------------------------------------------
       Comp<T> C;
+      constexpr bool PAIR = tree_pair_ok<T>();
+      T rowA[PAIR ? 2 * N : 1];                               // the first row of a pair waits here for its neighbour
       sfor_down<0, N>([&](auto J_) {
         constexpr int j = decltype(J_)::value;
         if constexpr (in_chain(j, h)) {
@@ -217,46 +255,93 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
               row[N + c] = T(0);
             }
           });
-          // image of row j for the 64 configurations, then 8n-byte segments to dc_du[b][j][:].  The
+          // image of a row for the 64 configurations, then 8n-byte segments to dc_du[b][row][:].  The
           // block is ONE wave and a wave's LDS operations execute in order, so a wave-level fence
           // (compiler ordering) is all the image needs -- no s_barrier, no wait on the previous
           // row's global stores.
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          {
-            V2* mine = reinterpret_cast<V2*>(rowimg) + lane * TREE_KP2;
-            sfor<0, N>([&](auto E_) {
-              constexpr int e = decltype(E_)::value;
-              V2 x; x[0] = row[2 * e]; x[1] = row[2 * e + 1];
-              mine[e] = x;
-            });
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-#ifdef RBD_TREE_EXP_NOFLUSH      // timing experiment: rows stay in the image (results are wrong)
-          if (factive && use_damping == 12345) {
-#else
-          if (factive) {
-#endif
-            if constexpr (WIDE && sizeof(T) == 4 && !RBD_TREE_NO_BUF_FLUSH) {
-              if (nvalid == 64) {
-                flush_image_rows_buf<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), out_rs, (fsub * (N * N / 2) + fe) * 16,
-                                                      j * 2 * N * (int)sizeof(T), N * 2 * N * (int)sizeof(T), fsub, fe);
-              } else {
-                flush_image_rows<CPI, TREE_KP / 4, false>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N)),
-                                                          (long long)(N * N / 2), fsub, fe, nvalid);
-              }
-            } else if constexpr (WIDE) {
-#ifdef RBD_TREE_EXP_L2ONLY       // timing experiment: every block writes block 0's region (stays in L2; results are wrong)
-              flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (0 * N + j) * (2 * N)),
-#else
-              flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + j) * (2 * N)),
-#endif
-                                                 (long long)(N * N / 2), fsub, fe, nvalid);
-            } else {
-              flush_image_rows<CPI, TREE_KP2>(reinterpret_cast<const V2*>(rowimg), reinterpret_cast<V2*>(dcdu + (cfg0 * N + j) * (2 * N)),
-                                              (long long)(N * N), fsub, fe, nvalid);
+          auto emit_single = [&](auto JR_, const T (&rw)[2 * N]) {
+            constexpr int jr = decltype(JR_)::value;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+              V2* mine = reinterpret_cast<V2*>(rowimg) + lane * TREE_KP2;
+              sfor<0, N>([&](auto E_) {
+                constexpr int e = decltype(E_)::value;
+                V2 x; x[0] = rw[2 * e]; x[1] = rw[2 * e + 1];
+                mine[e] = x;
+              });
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#ifdef RBD_TREE_EXP_NOFLUSH      // timing experiment: rows stay in the image (results are wrong)
+            if (factive && use_damping == 12345) {
+#else
+            if (factive) {
+#endif
+              if constexpr (WIDE && sizeof(T) == 4 && !RBD_TREE_NO_BUF_FLUSH) {
+                if (nvalid == 64) {
+                  flush_image_rows_buf<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), out_rs, (fsub * (N * N / 2) + fe) * 16,
+                                                        jr * 2 * N * (int)sizeof(T), N * 2 * N * (int)sizeof(T), fsub, fe);
+                } else {
+                  flush_image_rows<CPI, TREE_KP / 4, false>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + jr) * (2 * N)),
+                                                            (long long)(N * N / 2), fsub, fe, nvalid);
+                }
+              } else if constexpr (WIDE) {
+#ifdef RBD_TREE_EXP_L2ONLY       // timing experiment: every block writes block 0's region (stays in L2; results are wrong)
+                flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (0 * N + jr) * (2 * N)),
+#else
+                flush_image_rows<CPI, TREE_KP / 4>(reinterpret_cast<const V4*>(rowimg), reinterpret_cast<V4*>(dcdu + (cfg0 * N + jr) * (2 * N)),
+#endif
+                                                   (long long)(N * N / 2), fsub, fe, nvalid);
+              } else {
+                flush_image_rows<CPI, TREE_KP2>(reinterpret_cast<const V2*>(rowimg), reinterpret_cast<V2*>(dcdu + (cfg0 * N + jr) * (2 * N)),
+                                                (long long)(N * N), fsub, fe, nvalid);
+              }
+            }
+          };
+          constexpr int role = PAIR ? tree_pair_role(j) : 0;
+          if constexpr (role == 1) {
+            sfor<0, 2 * N>([&](auto E_) { constexpr int e = decltype(E_)::value; rowA[e] = row[e]; });
+          } else if constexpr (role == 2) {
+            if (nvalid == 64) {
+              // rows j (this one) and j + 1 (rowA) of 32 configurations at a time: [32][N 16-byte pieces (+ 1 pad)], row j first;
+              // a store instruction = TWO whole pairs (lanes 0 .. 2N-1: configuration 2 it + lane / N, piece lane % N)
+              constexpr int PV = TREE_PKP / 4;                          // image stride in 16-byte pieces (odd: conflict-free)
+              const int psub = lane / N, pe = lane - psub * N;          // (N <= 32: two configurations per instruction)
+              sfor<0, 2>([&](auto H_) {
+                constexpr int hh = decltype(H_)::value;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if ((lane >> 5) == hh) {
+                  V4* mine = reinterpret_cast<V4*>(rowimg) + (lane & 31) * PV;
+                  sfor<0, N / 2>([&](auto E_) {
+                    constexpr int e = decltype(E_)::value;
+                    V4 x; x[0] = row[4 * e]; x[1] = row[4 * e + 1]; x[2] = row[4 * e + 2]; x[3] = row[4 * e + 3];
+                    mine[e] = x;
+                    V4 y; y[0] = rowA[4 * e]; y[1] = rowA[4 * e + 1]; y[2] = rowA[4 * e + 2]; y[3] = rowA[4 * e + 3];
+                    mine[N / 2 + e] = y;
+                  });
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 2 * N) {
+                  typedef unsigned U4 __attribute__((ext_vector_type(4)));
+                  V4 buf[16];
+                  sfor<0, 16>([&](auto I_) { constexpr int it = decltype(I_)::value; buf[it] = reinterpret_cast<const V4*>(rowimg)[(2 * it + psub) * PV + pe]; });
+                  const int voff = (psub * (N * N / 2) + pe) * 16;
+                  sfor<0, 16>([&](auto I_) {
+                    constexpr int it = decltype(I_)::value;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(U4, buf[it]), out_rs, voff,
+                                                           ((32 * hh + 2 * it) * N + j) * 2 * N * (int)sizeof(T), 0);
+                  });
+                }
+              });
+            } else {       // a ragged tile: the two rows one after the other
+              emit_single(std::integral_constant<int, j + 1>{}, rowA);
+              emit_single(std::integral_constant<int, j>{}, row);
+            }
+          } else {
+            emit_single(std::integral_constant<int, j>{}, row);
           }
           // step back to the parent inside the chain, or park the finished chain's composite
           if constexpr (j != h) {
