@@ -326,8 +326,9 @@ __global__ __launch_bounds__(64 * TREE_W, 1) void rnea_grad_tree_kernel(const T*
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 2 * N) {
                   typedef unsigned U4 __attribute__((ext_vector_type(4)));
-                  V4 buf[16];
-                  sfor<0, 16>([&](auto I_) { constexpr int it = decltype(I_)::value; buf[it] = reinterpret_cast<const V4*>(rowimg)[(2 * it + psub) * PV + pe]; });
+                  typedef float F4 __attribute__((ext_vector_type(4)));      // (the pair path is fp32 only; F4 keeps this branch well-formed for T = double)
+                  F4 buf[16];
+                  sfor<0, 16>([&](auto I_) { constexpr int it = decltype(I_)::value; buf[it] = reinterpret_cast<const F4*>(rowimg)[(2 * it + psub) * PV + pe]; });
                   const int voff = (psub * (N * N / 2) + pe) * 16;
                   sfor<0, 16>([&](auto I_) {
                     constexpr int it = decltype(I_)::value;
