@@ -97,15 +97,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? RBD_FDP_MINW : 1) void fd_pre_
       constexpr int p = PARENT[i];
       constexpr int si = s_index(i);
       sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[i][r] = IA[i][sy(r, si)]; });   // U = IA S
-#ifdef RBD_FDP_RCP
-      {   // v_rcp_f32 (1 ulp) + one Newton step: D is a positive, well-scaled inertia -- no denormal / overflow handling needed
-        const T d = U[i][si];
-        T r0 = __builtin_amdgcn_rcpf(d);
-        Dinv[i] = fma_(fma_(-d, r0, T(1)), r0, r0);
-      }
-#else
-      Dinv[i] = T(1) / U[i][si];                                                                // 1 / (S^T U)
-#endif
+      Dinv[i] = rcp_inertia(U[i][si]);                                                            // 1 / (S^T U): v_rcp_f32 + one Newton step in fp32 (rbd_spatial.h)
 #ifdef RBD_FDP_EXP_NOIA
       if constexpr (false) {
 #else

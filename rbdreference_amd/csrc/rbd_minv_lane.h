@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 && grad_max_rows() <= 8) ? 2 : 
         constexpr int p = PARENT[i];
         constexpr int si = s_index(i);
         sfor<0, 6>([&](auto R) { constexpr int r = decltype(R)::value; U[i][r] = IA[i][sy(r, si)]; });   // U = IA S
-        Dinv[i] = T(1) / U[i][si];                                                                        // 1 / (S^T U)
+        Dinv[i] = rcp_inertia(U[i][si]);                                                                  // 1 / (S^T U)
         if constexpr (p >= 0) {
           T A[6][6];   // A = X^T Ia, Ia = IA - U U^T / D
           sfor<0, 6>([&](auto C) {
