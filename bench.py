@@ -638,7 +638,7 @@ def main():
                 t4 = time_extra_ms(lambda: rf.forward_dynamics_grad(qf, qdf, qddf), 5, 1)
                 extra["floating_quadruped_forward_dynamics_grad_B65536_f32_api"] = {
                     "ms_per_call": t4, "evals_per_s": Bf / (t4 * 1e-3), "alg_GBps": Bf * (3 * nvf + 2 * nvf * nvf) * 4 / (t4 * 1e-3) / 1e9,
-                    "kernels": "rnea_fbw + minv_fbm + fb_apply + rnea_grad_fbw + neg_mm_kernel<float,18>"}
+                    "kernels": "minv_fbm (bias force, Minv, qdd in one launch) + rnea_grad_fbw + neg_mm_kernel<float,18>"}
             except Exception as e:  # the headline line must still be printed
                 extra["error"] = repr(e)
             try:
@@ -653,15 +653,37 @@ def main():
                     NG = 50
                     gs = GraphSteps(ss, NG, dev)
                     msg = time_extra_ms(gs, 20, 3) / NG
+                    # the same independent launches issued on TWO streams alternately (two rotating buffer sets): the row stores
+                    # of one launch overlap the arithmetic of the next.  Information only: the headline and --gpus N use one stream
+                    # (one kernel at a time is what the roofline fields and the rocprof stats describe).
+                    ss2 = GradStep(rbd, [(qs, qds, qdds), (qs, qds, qdds)])
+                    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+                    def two_streams(n=50):
+                        for k in range(n):
+                            ss2.on_stream((sa if k & 1 else sb).cuda_stream)
+                        sa.synchronize(); sb.synchronize()
+
+                    def wall_ms(fn, n):
+                        fn(n); best = 1e30
+                        for _ in range(5):
+                            t0 = time.perf_counter(); fn(n); best = min(best, (time.perf_counter() - t0) / n * 1e3)
+                        return best
+                    ms2 = wall_ms(two_streams, 200)
                 extra["cfg3_per_rank_shard_B131072_of_1M_f32"] = {
                     "ms_per_launch": ms, "evals_per_s": Bs / (ms * 1e-3), "alg_GBps": Bs * BYTES_PER_EVAL / (ms * 1e-3) / 1e9,
                     "kernel": kn, "predicted_8gpu_strong_scaling_evals_per_s": (1 << 20) / (ms * 1e-3),
                     "ms_per_launch_graph": msg, "alg_GBps_graph": Bs * BYTES_PER_EVAL / (msg * 1e-3) / 1e9,
                     "predicted_8gpu_strong_scaling_evals_per_s_graph": (1 << 20) / (msg * 1e-3),
+                    "ms_per_launch_two_streams": ms2, "alg_GBps_two_streams": Bs * BYTES_PER_EVAL / (ms2 * 1e-3) / 1e9,
+                    "predicted_8gpu_strong_scaling_evals_per_s_two_streams": (1 << 20) / (ms2 * 1e-3),
                     "note": "one rank's share of the 1 048 576-row global batch; 8 ranks run it concurrently with no "
                             "data-path collective, so the N = 8 strong-scaling value is bounded by (1 M rows) / this time.  "
                             "`_graph`: the same launches replayed from one HIP graph of 50 (what bench.py --gpus N > 1 times "
-                            "in strong mode: the launch path leaves the step)"}
+                            "in strong mode: the launch path leaves the step).  `_two_streams`: the same independent launches "
+                            "issued alternately on two streams (wall clock over 200 launches): a launch's row stores overlap the "
+                            "next launch's arithmetic -- what a consumer with independent batches can have; not what the headline "
+                            "or --gpus N measure"}
                 del gs
                 del ss
             except Exception as e:
@@ -685,7 +707,7 @@ def main():
                         "cfg4_quadruped_rnea_grad+minv_B65536_f64": ("", ["rnea_grad_kernel<double,true,false>", "minv_lane_kernel<double>"], 65536 * 3840),
                         "iiwa_forward_dynamics_grad_B1048576_f32_api": ("", ["fd_pre_kernel<float>", "rnea_grad_idsva_pipe_kernel<float,true,true>"], (1 << 20) * (3 * 7 + 2 * 49) * 4),
                         "atlas_forward_dynamics_grad_B16384_f32_api": ("", ["rnea_kernel<float,false,false>", "minv_fused_kernel<float>", "rnea_grad_tree_kernel<float,true>", "neg_mm_kernel<float,30>"], 16384 * (3 * 30 + 2 * 900) * 4),
-                        "floating_quadruped_forward_dynamics_grad_B65536_f32_api": ("", ["rnea_fbw_kernel<float,false,0>", "minv_fbm_kernel<float>", "fb_apply_kernel<float>", "rnea_grad_fbw_kernel<float,true>", "neg_mm_kernel<float,18>"], 65536 * (3 * nvq + 2 * nvq * nvq) * 4),
+                        "floating_quadruped_forward_dynamics_grad_B65536_f32_api": ("", ["minv_fbm_kernel<float>", "rnea_grad_fbw_kernel<float,true>", "neg_mm_kernel<float,18>"], 65536 * (3 * nvq + 2 * nvq * nvq) * 4),
                     }
                     fbq = {"_rnea": (["rnea_fbw_kernel<float,true,0>"], 65536 * (4 * nvq + 18 * nbq) * 4),
                            "_minv": (["minv_fbm_kernel<float>"], 65536 * (nvq + nvq * nvq) * 4),
